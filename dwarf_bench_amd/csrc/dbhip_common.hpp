@@ -1,0 +1,124 @@
+// dbhip_common.hpp — shared device/host helpers for the gfx950 dwarf kernels.
+// Wave = 64 lanes everywhere (CDNA4); nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dbhip.h"
+
+namespace dbhip {
+
+constexpr int kWave = 64;
+
+// native 16-byte vectors (clang ext_vector_type: usable with __builtin_nontemporal_load/store)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr size_t kWsAlign = 256;   // workspace alignment required from callers
+constexpr size_t kWsHeader = 256;  // [0] status word, rest reserved; cleared by every call
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------
+struct DeviceInfo {
+  int cus = 0;
+  int wave = 0;
+  bool ok = false;
+};
+const DeviceInfo &current_device_info();  // cached per device (dbhip_util.hip)
+
+inline hipStream_t as_stream(dbhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool ws_ok(const void *ws, size_t have, size_t need) {
+  return ws != nullptr && (reinterpret_cast<uintptr_t>(ws) % kWsAlign) == 0 && have >= need;
+}
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+// Blocks per CU a PERSISTENT grid may count on being co-resident (look-back kernels wait on lower
+// tiles, so the grid must never exceed residency).  `want` is capped at 5: ROCm 7.2's occupancy API
+// over-reports by one block per CU only where SGPR use limits a 256-thread kernel to 6-7 blocks
+// (MI355X_MICROARCH "Residency and cooperative launch"), so min(API, want <= 5) is always resident.
+template <typename Kernel>
+inline int resident_blocks_per_cu(Kernel kernel, int threads, size_t dynamic_lds, int want) {
+  int api = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, threads, dynamic_lds) != hipSuccess ||
+      api < 1)
+    api = 1;
+  if (want > 5) want = 5;
+  if (want < 1) want = 1;
+  return api < want ? api : want;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of `mask` in lanes below the calling lane
+__device__ __forceinline__ unsigned mbcnt(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+}
+
+// Inclusive wave64 prefix sum in 6 DPP steps: row_shr 1/2/4/8 inside each 16-lane row, then
+// row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2 and 3 (gfx9/CDNA DPP controls).
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ unsigned wave_reduce_add(unsigned v) {
+  return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63);
+}
+
+__device__ __forceinline__ unsigned long long wave_reduce_add_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// agent-scope relaxed accesses: lowered to global_load/store ... sc1 (bypass the per-CU L1 and the
+// non-coherent per-XCD L2), the only forms another workgroup's data may be exchanged through
+// inside one launch (MI355X_MICROARCH "inter-workgroup visibility").
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// splitmix64-style counter hash shared with oracle/dbo_gen.c (must stay bit-identical)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t i) {
+  uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+
+// Murmur3 32-bit finaliser: the slot/partition hash of the join and group-by tables.
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+}  // namespace dbhip

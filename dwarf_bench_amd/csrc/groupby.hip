@@ -1,0 +1,202 @@
+// groupby.hip — dwarf 3: GROUP BY key, SUM(val) into the dense output[key] for gfx950.
+//
+// Replaces GroupBy's two kernels (groupby/groupby.cpp:58-93: a global open-addressing table of n
+// slots hit with one CAS + one fetch_add per row, then n redundant lookups + atomic stores) with the
+// privatised design the reference itself sketches in GroupByLocal (groupby/groupby_local.cpp:58-112:
+// one private table per executor + merge): here the private table is the workgroup's LDS.
+// Logical result identical to expected_GroupBy (groupby/groupby.cpp:8-19), uint32 wrap-around sums.
+//
+//   gb_aggregate  persistent workgroups stream (key, val) with 16-byte-per-lane loads and add into an
+//                 LDS table indexed by key (identity hash = the reference's SimpleHasher key % groups,
+//                 hashfunctions.hpp:43-49; keys are < groups by the dense-output contract, so a slot
+//                 never collides).  A table holds at most 32768 groups (128 KiB of the 160 KiB LDS):
+//                 for more groups the key space is cut into R ranges and workgroup (x, r) aggregates
+//                 only range r of chunk x — partner workgroups read the same rows at about the same
+//                 time, so the second read is served by L2 / Infinity Cache, not HBM.  Tiny group
+//                 counts replicate the table across lanes to spread same-address LDS atomics.
+//   gb_reduce     sums the per-workgroup partial tables into output[] (plain coalesced loads, no
+//                 global atomics: memory-side atomics are ~5x slower than stores on this chip).
+//
+// Algorithmic HBM bytes: 8*n (keys + vals) + 4*groups; partial tables add slots*groups*4*2.
+#include "dbhip_common.hpp"
+
+namespace dbhip {
+namespace {
+
+constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table
+constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table is large
+constexpr int kGbSmallThreads = 256;
+constexpr int kGbSmallLdsWords = 8192;  // <= 32 KiB tables run 256-thread workgroups, 4 per CU
+constexpr int kGbVecPerIter = 2;        // uint4 key + uint4 val loads in flight per lane per step
+
+struct GbHeader {
+  unsigned status;
+  unsigned pad[63];
+};
+static_assert(sizeof(GbHeader) == kWsHeader, "workspace header size");
+
+struct GbGeometry {
+  unsigned ranges;       // R key ranges
+  unsigned range_groups; // groups per range (last may be short)
+  unsigned replicas;     // lane-replicated copies of the table (tiny group counts)
+  unsigned threads;      // workgroup size
+  unsigned chunk_slots;  // workgroups per range = partial tables per range
+  unsigned lds_words;
+};
+
+inline GbGeometry gb_geometry(uint32_t groups, int cus) {
+  GbGeometry g;
+  g.ranges = (groups + kGbMaxLdsGroups - 1) / kGbMaxLdsGroups;
+  if (g.ranges == 0) g.ranges = 1;
+  g.range_groups = (groups + g.ranges - 1) / g.ranges;
+  if (g.range_groups == 0) g.range_groups = 1;
+  g.replicas = 1;
+  if (g.range_groups <= 256) {  // spread same-address LDS atomics over lane-private copies
+    g.replicas = 32;
+    while (g.replicas > 1 && g.range_groups * g.replicas > kGbSmallLdsWords) g.replicas /= 2;
+  }
+  g.lds_words = g.range_groups * g.replicas;
+  const bool small = g.lds_words <= kGbSmallLdsWords;
+  g.threads = small ? kGbSmallThreads : kGbBigThreads;
+  const unsigned per_cu = small ? 4u : 1u;
+  unsigned total = static_cast<unsigned>(cus) * per_cu;
+  g.chunk_slots = total / g.ranges;
+  if (g.chunk_slots == 0) g.chunk_slots = 1;
+  return g;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
+    const u32x4 *__restrict__ keys4, const u32x4 *__restrict__ vals4, const unsigned *__restrict__ keys,
+    const unsigned *__restrict__ vals, size_t n, unsigned groups, GbGeometry geo,
+    unsigned *__restrict__ partials, GbHeader *hdr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_table[];
+  const unsigned tid = threadIdx.x;
+  // blocks b and b+8 tend to share an XCD (round-robin dispatch): give them the same rows and
+  // different key ranges so the partner's read hits the XCD's L2.  Placement only affects speed.
+  const unsigned b = blockIdx.x;
+  unsigned slot, range;
+  if (geo.ranges > 1 && (gridDim.x % (8 * geo.ranges)) == 0) {
+    range = (b / 8) % geo.ranges;
+    slot = (b % 8) + 8 * (b / (8 * geo.ranges));
+  } else {
+    range = b % geo.ranges;
+    slot = b / geo.ranges;
+  }
+  const unsigned lo = range * geo.range_groups;
+  const unsigned hi_excl = lo + geo.range_groups < groups ? lo + geo.range_groups : groups;
+  const unsigned span = hi_excl > lo ? hi_excl - lo : 0;
+  const unsigned rep_off = (tid % geo.replicas) * geo.range_groups;
+
+  for (unsigned i = tid; i < geo.lds_words; i += THREADS) s_table[i] = 0;
+  __syncthreads();
+
+  bool bad_key = false;
+  const size_t n4 = n / 4;
+  const size_t step = static_cast<size_t>(geo.chunk_slots) * THREADS * kGbVecPerIter;
+  for (size_t base = static_cast<size_t>(slot) * THREADS * kGbVecPerIter; base < n4; base += step) {
+    u32x4 k[kGbVecPerIter], v[kGbVecPerIter];
+#pragma unroll
+    for (int u = 0; u < kGbVecPerIter; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * THREADS + tid;
+      if (i < n4) {
+        k[u] = __builtin_nontemporal_load(keys4 + i);
+        v[u] = __builtin_nontemporal_load(vals4 + i);
+      } else {
+        k[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kGbVecPerIter; ++u) {
+      const unsigned kk[4] = {k[u].x, k[u].y, k[u].z, k[u].w};
+      const unsigned vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      const bool live = base + static_cast<size_t>(u) * THREADS + tid < n4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned rel = kk[c] - lo;
+        if (rel < span) atomicAdd(&s_table[rep_off + rel], vv[c]);
+        bad_key |= live && kk[c] >= groups;
+      }
+    }
+  }
+  // the n % 4 tail rows: first workgroup of every range
+  if (slot == 0 && tid < (n & 3)) {
+    const unsigned kk = keys[n4 * 4 + tid], vv = vals[n4 * 4 + tid];
+    const unsigned rel = kk - lo;
+    if (rel < span) atomicAdd(&s_table[rep_off + rel], vv);
+    bad_key |= kk >= groups;
+  }
+  if (bad_key && range == 0) atomicOr(&hdr->status, DBHIP_DEV_KEY_RANGE);
+  __syncthreads();
+
+  // partial table of this workgroup: partials[range][slot][range_groups]
+  unsigned *dst = partials + (static_cast<size_t>(range) * geo.chunk_slots + slot) * geo.range_groups;
+  for (unsigned g = tid; g < geo.range_groups; g += THREADS) {
+    unsigned sum = 0;
+    for (unsigned r = 0; r < geo.replicas; ++r) sum += s_table[r * geo.range_groups + g];
+    dst[g] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void gb_reduce_kernel(const unsigned *__restrict__ partials,
+                                                        GbGeometry geo, unsigned groups,
+                                                        unsigned *__restrict__ out) {
+  const unsigned g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const unsigned range = g / geo.range_groups, rel = g % geo.range_groups;
+  const unsigned *p = partials + static_cast<size_t>(range) * geo.chunk_slots * geo.range_groups + rel;
+  unsigned sum = 0;
+  for (unsigned s = 0; s < geo.chunk_slots; ++s) sum += p[static_cast<size_t>(s) * geo.range_groups];
+  out[g] = sum;
+}
+
+}  // namespace
+}  // namespace dbhip
+
+using namespace dbhip;
+
+extern "C" size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t groups) {
+  (void)n;
+  // sized for the largest device this library targets (256 CUs x 4 workgroups) so the query
+  // needs no device; the launch uses the actual CU count.
+  const GbGeometry g = gb_geometry(groups ? groups : 1, 256);
+  const size_t partial_words = static_cast<size_t>(g.ranges) * g.chunk_slots * g.range_groups;
+  return align_up(kWsHeader + partial_words * sizeof(unsigned), kWsAlign);
+}
+
+extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n,
+                                     uint32_t groups, uint32_t *out, void *workspace,
+                                     size_t workspace_bytes, dbhip_stream_t stream) {
+  if (groups == 0) return n == 0 ? DBHIP_OK : DBHIP_EINVAL;
+  if (!out || (n && (!keys || !vals))) return DBHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(vals)) & 15u) return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  const int cus = dev.cus < 256 ? dev.cus : 256;
+  const GbGeometry geo = gb_geometry(groups, cus);
+  const size_t partial_words = static_cast<size_t>(geo.ranges) * geo.chunk_slots * geo.range_groups;
+  if (!ws_ok(workspace, workspace_bytes, kWsHeader + partial_words * sizeof(unsigned)))
+    return DBHIP_EWORKSPACE;
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(workspace, 0, kWsHeader, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  GbHeader *hdr = static_cast<GbHeader *>(workspace);
+  unsigned *partials = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + kWsHeader);
+  const unsigned grid = geo.ranges * geo.chunk_slots;
+  const size_t lds = static_cast<size_t>(geo.lds_words) * sizeof(unsigned);
+  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys), *v4 = reinterpret_cast<const u32x4 *>(vals);
+  if (geo.threads == kGbBigThreads) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kGbMaxLdsGroups * 4);
+    if (e != hipSuccess) return static_cast<int>(e);
+    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
+                       v4, keys, vals, n, groups, geo, partials, hdr);
+  } else {
+    hipLaunchKernelGGL((gb_aggregate_kernel<kGbSmallThreads>), dim3(grid), dim3(kGbSmallThreads), lds, s,
+                       k4, v4, keys, vals, n, groups, geo, partials, hdr);
+  }
+  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, partials, geo, groups,
+                     out);
+  return launch_status();
+}

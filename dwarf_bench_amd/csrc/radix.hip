@@ -1,0 +1,332 @@
+// radix.hip — dwarf 2: LSD radix sort of 32-bit keys for gfx950, one sweep per digit.
+//
+// Replaces oneDPL's std::sort(device_policy) behind Radix/RadixCuda (dpl_wrapper.hpp:35-39 <-
+// sort/radix.cpp:34); result identical to std::sort (sort/radix.cpp:8-12).
+//
+// Structure (digit width BITS = 8 tuned, 4 = the configuration named in BASELINE.json):
+//   1. rs_histogram   one read of the keys: global digit totals for EVERY pass (LDS histograms per
+//                     workgroup, one coalesced atomic flush per workgroup).
+//   2. rs_plan        one workgroup: per pass the exclusive digit bases, and which passes are skipped
+//                     because their digit is constant over the whole input (e.g. keys in [1,10000]
+//                     skip the two upper bytes); fixes the ping-pong parity of every pass.
+//   3. rs_sweep x P   ONE kernel per executed pass: a persistent grid walks 4096-key tiles; each wave
+//                     ranks its 1024 keys stably with wave64 match masks (BITS ballots per key,
+//                     v_mbcnt for the lane rank, wave-private LDS digit counters), the tile is
+//                     re-ordered by digit through LDS, per-digit tile offsets come from a decoupled
+//                     look-back over 4-byte {state,count} granules (lookback.hpp), and the tile is
+//                     written out in digit order so consecutive lanes hit consecutive addresses.
+//   4. rs_finalize    copies tmp -> keys when an odd number of passes ran.
+//
+// Bytes: 4N (histogram) + P * 8N (sweeps), P <= 32/BITS; everything between passes stays device-side
+// (no host round trip: skipped passes return at once on a device-side flag).
+#include "dbhip_common.hpp"
+#include "lookback.hpp"
+
+namespace dbhip {
+namespace {
+
+constexpr int kRsThreads = 256;
+constexpr int kRsWaves = kRsThreads / kWave;
+constexpr int kRsKpt = 16;                       // keys per lane per tile
+constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
+constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 4096 keys
+constexpr int kRsMaxPasses = 8;
+constexpr int kRsMaxRadix = 256;
+
+struct RsPass {
+  unsigned skip;        // digit constant over the input: the sweep returns immediately
+  unsigned src_is_tmp;  // which buffer holds the keys when this pass starts
+};
+struct RsHeader {
+  unsigned status;
+  unsigned final_in_tmp;
+  unsigned pad0[6];
+  RsPass pass[kRsMaxPasses];
+  unsigned pad1[64 - 8 - 2 * kRsMaxPasses];
+};
+static_assert(sizeof(RsHeader) == kWsHeader, "workspace header size");
+
+// workspace: header | totals[8][256] | bases[8][256] | granules[passes][tiles][radix]
+constexpr size_t kRsTotalsOff = kWsHeader;
+constexpr size_t kRsBasesOff = kRsTotalsOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
+constexpr size_t kRsGranulesOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
+
+// lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA)
+template <int BITS>
+__device__ __forceinline__ unsigned long long match_digit(unsigned d) {
+  unsigned long long m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
+                                                                  size_t n, unsigned xor_mask,
+                                                                  unsigned *__restrict__ totals) {
+  constexpr int kRadix = 1 << BITS;
+  constexpr int kPasses = 32 / BITS;
+  __shared__ unsigned s_hist[kPasses * kRadix];
+  for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) s_hist[i] = 0;
+  __syncthreads();
+  const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
+  const size_t n4 = n / 4;
+  const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kRsThreads + threadIdx.x; i < n4; i += stride) {
+    const uint4 v = k4[i];
+    const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int p = 0; p < kPasses; ++p)
+        atomicAdd(&s_hist[p * kRadix + ((k[c] >> (p * BITS)) & (kRadix - 1))], 1u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+    const unsigned k = keys[n4 * 4 + threadIdx.x] ^ xor_mask;
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p)
+      atomicAdd(&s_hist[p * kRadix + ((k >> (p * BITS)) & (kRadix - 1))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) {
+    const unsigned c = s_hist[i];
+    if (c) atomicAdd(&totals[(i / kRadix) * kRsMaxRadix + (i % kRadix)], c);
+  }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void rs_plan_kernel(size_t n, RsHeader *hdr,
+                                                             const unsigned *__restrict__ totals,
+                                                             unsigned *__restrict__ bases) {
+  constexpr int kRadix = 1 << BITS;
+  constexpr int kPasses = 32 / BITS;
+  __shared__ unsigned s_wsum[kRsWaves];
+  __shared__ unsigned s_skip[kPasses];
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (tid < kPasses) s_skip[tid] = 0;
+  __syncthreads();
+  for (int p = 0; p < kPasses; ++p) {
+    const unsigned t = tid < kRadix ? totals[p * kRsMaxRadix + tid] : 0u;
+    if (t == n) s_skip[p] = 1;
+    const unsigned incl = wave_inclusive_scan(t);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned off = 0;
+    for (unsigned w = 0; w < wave; ++w) off += s_wsum[w];
+    if (tid < kRadix) bases[p * kRsMaxRadix + tid] = off + incl - t;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    unsigned cur = 0;
+    for (int p = 0; p < kPasses; ++p) {
+      hdr->pass[p].skip = s_skip[p];
+      hdr->pass[p].src_is_tmp = cur;
+      if (!s_skip[p]) cur ^= 1u;
+    }
+    hdr->final_in_tmp = cur;
+  }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys, unsigned *tmp, size_t n,
+                                                              int pass, unsigned xor_mask,
+                                                              RsHeader *hdr,
+                                                              const unsigned *__restrict__ bases,
+                                                              unsigned *granules, size_t num_tiles) {
+  constexpr int kRadix = 1 << BITS;
+  __shared__ unsigned s_cnt[kRsWaves][kRadix];  // per-wave digit counts, then wave-exclusive offsets
+  __shared__ unsigned s_dexcl[kRadix];          // tile-local exclusive offset of each digit
+  __shared__ unsigned s_goff[kRadix];           // global offset of a digit minus its local offset
+  __shared__ unsigned s_wsum[kRsWaves];
+  __shared__ unsigned s_keys[kRsTile];
+
+  const RsPass plan = hdr->pass[pass];
+  if (plan.skip) return;  // uniform over the grid
+  const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
+  unsigned *__restrict__ dst = plan.src_is_tmp ? keys : tmp;
+  const int shift = pass * BITS;
+  const unsigned *dbase = bases + pass * kRsMaxRadix;
+
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned long long lanes_lt = (1ull << lane) - 1ull;
+
+  for (size_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const size_t tile_base = tile * kRsTile;
+    const unsigned valid_in_tile =
+        static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
+    const unsigned wave_first = wave * kRsWaveKeys + lane;
+
+    unsigned key[kRsKpt];
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      const unsigned idx = wave_first + j * kWave;
+      key[j] = idx < valid_in_tile ? src[tile_base + idx] : 0xFFFFFFFFu;
+    }
+    for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    // ---- stable rank of every key among the keys of its wave with the same digit
+    unsigned rank[kRsKpt];
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      const bool valid = wave_first + j * kWave < valid_in_tile;
+      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      const unsigned long long m = match_digit<BITS>(d) & __ballot(valid);
+      const unsigned prior = __builtin_popcountll(m & lanes_lt);
+      const unsigned c = s_cnt[wave][d];  // same address inside a digit group: LDS broadcast
+      rank[j] = c + prior;
+      if (valid && prior == 0) s_cnt[wave][d] = c + __builtin_popcountll(m);  // group leader
+    }
+    __syncthreads();
+
+    // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals, granule
+    unsigned tile_count = 0;
+    if (tid < kRadix) {
+#pragma unroll
+      for (int w = 0; w < kRsWaves; ++w) {
+        const unsigned c = s_cnt[w][tid];
+        s_cnt[w][tid] = tile_count;
+        tile_count += c;
+      }
+      st_agent(granules + tile * kRadix + tid,
+               (tile == 0 ? kLb32Inclusive : kLb32Aggregate) | tile_count);
+    }
+    const unsigned incl = wave_inclusive_scan(tile_count);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned dexcl = incl - tile_count;
+    for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
+    if (tid < kRadix) s_dexcl[tid] = dexcl;
+    __syncthreads();
+
+    // ---- re-order the tile by digit in LDS
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      if (wave_first + j * kWave < valid_in_tile) {
+        const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+        s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
+      }
+    }
+    // ---- global offset of each digit of this tile (look-back latency overlaps the LDS writes)
+    if (tid < kRadix) {
+      unsigned excl = 0;
+      if (tile != 0) {
+        excl = lookback_column32(granules, tile, kRadix, tid, &hdr->status);
+        st_agent(granules + tile * kRadix + tid, kLb32Inclusive | ((excl + tile_count) & kLb32Value));
+      }
+      s_goff[tid] = dbase[tid] + excl - dexcl;
+    }
+    __syncthreads();
+
+    // ---- write out in digit order: consecutive lanes -> consecutive addresses inside a digit run
+#pragma unroll
+    for (int k = 0; k < kRsKpt; ++k) {
+      const unsigned p = k * kRsThreads + tid;
+      if (p < valid_in_tile) {
+        const unsigned kk = s_keys[p];
+        const unsigned d = ((kk ^ xor_mask) >> shift) & (kRadix - 1);
+        dst[s_goff[d] + p] = kk;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__restrict__ keys,
+                                                                 const unsigned *__restrict__ tmp,
+                                                                 size_t n, const RsHeader *hdr) {
+  if (!hdr->final_in_tmp) return;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
+  const size_t n4 = n / 4;
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(tmp);
+  uint4 *d4 = reinterpret_cast<uint4 *>(keys);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kRsThreads + threadIdx.x; i < n4; i += stride)
+    d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) keys[n4 * 4 + threadIdx.x] = tmp[n4 * 4 + threadIdx.x];
+}
+
+inline int rs_blocks_per_cu() {
+  static const int v = [] {
+    const char *e = getenv("DBHIP_SORT_BLOCKS_PER_CU");
+    int x = e ? atoi(e) : 0;
+    return (x >= 1 && x <= 6) ? x : 4;
+  }();
+  return v;
+}
+
+template <int BITS>
+int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, void *workspace,
+                    hipStream_t s, const DeviceInfo &dev) {
+  constexpr int kPasses = 32 / BITS;
+  constexpr int kRadix = 1 << BITS;
+  const size_t tiles = (n + kRsTile - 1) / kRsTile;
+  char *base = static_cast<char *>(workspace);
+  RsHeader *hdr = reinterpret_cast<RsHeader *>(base);
+  unsigned *totals = reinterpret_cast<unsigned *>(base + kRsTotalsOff);
+  unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
+  unsigned *granules = reinterpret_cast<unsigned *>(base + kRsGranulesOff);
+  const size_t gran_bytes = sizeof(unsigned) * kPasses * tiles * kRadix;
+
+  hipError_t e = hipMemsetAsync(workspace, 0, kRsGranulesOff + gran_bytes, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+
+  const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
+  const size_t cap = static_cast<size_t>(dev.cus) * 4;
+  const unsigned hgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+  hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hgrid), dim3(kRsThreads), 0, s, keys, n,
+                     xor_mask, totals);
+  hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
+  const size_t scap = static_cast<size_t>(dev.cus) *
+                      resident_blocks_per_cu(rs_sweep_kernel<BITS>, kRsThreads, 0, rs_blocks_per_cu());
+  const unsigned sgrid = static_cast<unsigned>(tiles < scap ? tiles : scap);
+  for (int p = 0; p < kPasses; ++p)
+    hipLaunchKernelGGL((rs_sweep_kernel<BITS>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                       xor_mask, hdr, bases, granules + static_cast<size_t>(p) * tiles * kRadix,
+                       tiles);
+  hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
+  return launch_status();
+}
+
+int radix_sort_entry(unsigned *keys, unsigned *tmp, size_t n, int radix_bits, unsigned xor_mask,
+                     void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
+  if (radix_bits != 4 && radix_bits != 8) return DBHIP_EINVAL;
+  if (n >= (1ull << 30)) return DBHIP_EINVAL;  // 30-bit granule values
+  if (n == 0) return DBHIP_OK;
+  if (!keys || !tmp) return DBHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) return DBHIP_EINVAL;
+  if (!ws_ok(workspace, workspace_bytes, dbhip_radix_sort_workspace_bytes(n, radix_bits)))
+    return DBHIP_EWORKSPACE;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  return radix_bits == 8
+             ? radix_sort_impl<8>(keys, tmp, n, xor_mask, workspace, as_stream(stream), dev)
+             : radix_sort_impl<4>(keys, tmp, n, xor_mask, workspace, as_stream(stream), dev);
+}
+
+}  // namespace
+}  // namespace dbhip
+
+using namespace dbhip;
+
+extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
+  if (radix_bits != 4 && radix_bits != 8) return 0;
+  const size_t tiles = (n + kRsTile - 1) / kRsTile;
+  const size_t passes = 32 / radix_bits, radix = static_cast<size_t>(1) << radix_bits;
+  return align_up(kRsGranulesOff + sizeof(unsigned) * passes * (tiles ? tiles : 1) * radix, kWsAlign);
+}
+
+extern "C" int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits,
+                                    void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
+  return radix_sort_entry(keys, tmp, n, radix_bits, 0u, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits,
+                                    void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
+  // signed order = unsigned order with the sign bit flipped (applied on the fly, keys unchanged)
+  return radix_sort_entry(reinterpret_cast<unsigned *>(keys), reinterpret_cast<unsigned *>(tmp), n,
+                          radix_bits, 0x80000000u, workspace, workspace_bytes, stream);
+}

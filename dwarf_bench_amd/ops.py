@@ -1,0 +1,224 @@
+"""Tensor-level front door to the gfx950 dwarf kernels.
+
+PyTorch is plumbing here (device memory, the current HIP stream, torch.distributed); every op is one or
+more calls through the C ABI of include/dbhip.h into libdbhip.so.  Nothing in this module computes on
+the host or falls back to torch ops: without the built library the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+DEV_OK, DEV_SPIN_TIMEOUT, DEV_KEY_RANGE, DEV_TABLE_FULL = 0, 1, 2, 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous {dtype} tensor on the GPU, got {t.dtype} on {t.device}")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    # torch's caching allocator hands out >= 512-byte aligned blocks; the C ABI asks for 256
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def workspace_status(ws: torch.Tensor) -> int:
+    """Device-side status word of a workspace (synchronises the current stream)."""
+    st = C.c_uint32(0xFFFFFFFF)
+    _capi.check(_capi.lib().dbhip_workspace_status(ws.data_ptr(), C.byref(st), _stream()), "workspace_status")
+    return st.value
+
+
+def _check_status(ws: torch.Tensor, what: str) -> None:
+    st = workspace_status(ws)
+    if st != DEV_OK:
+        raise _capi.DbhipError(f"{what}: device status {st:#x}")
+
+
+def device_info(device: int = 0):
+    name = C.create_string_buffer(64)
+    cus, wave = C.c_int(0), C.c_int(0)
+    _capi.check(_capi.lib().dbhip_device_info(device, name, 64, C.byref(cus), C.byref(wave)), "device_info")
+    return name.value.decode(), cus.value, wave.value
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic synthetic columns
+# ---------------------------------------------------------------------------------------------
+def gen_uniform_u32(n: int, seed: int, lo: int, hi: int, first_index: int = 0, device="cuda",
+                    dtype: torch.dtype = torch.int32) -> torch.Tensor:
+    """lo + mix64(seed, first_index + i) % (hi - lo + 1); dtype int32 reinterprets the uint32 bits."""
+    out = torch.empty(n, dtype=dtype, device=device)
+    _capi.check(_capi.lib().dbhip_gen_uniform_u32(out.data_ptr(), n, seed, first_index, lo, hi, _stream()),
+                "gen_uniform_u32")
+    return out
+
+
+def gen_unique_sorted_u32(n: int, seed: int, first_index: int = 0, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    _capi.check(_capi.lib().dbhip_gen_unique_sorted_u32(out.data_ptr(), n, seed, first_index, _stream()),
+                "gen_unique_sorted_u32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# dwarf 1: scan / compaction
+# ---------------------------------------------------------------------------------------------
+class CopyIfLt:
+    """Reusable plan for out = [x in src : x < filter]: owns workspace + output buffers for a size."""
+
+    def __init__(self, n: int, device="cuda"):
+        self.n = n
+        lib = _capi.lib()
+        self.ws_bytes = lib.dbhip_copy_if_lt_i32_workspace_bytes(n)
+        self.ws = _ws(self.ws_bytes, device)
+        self.out = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+        self.out_size = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def launch(self, src: torch.Tensor, filter_value: int) -> None:
+        """Asynchronous on the current stream; nothing is read back."""
+        _need(src, torch.int32, "src")
+        if src.numel() != self.n:
+            raise ValueError("size mismatch")
+        _capi.check(_capi.lib().dbhip_copy_if_lt_i32(src.data_ptr(), self.n, filter_value, self.out.data_ptr(),
+                                                     self.out_size.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                     _stream()), "copy_if_lt_i32")
+
+    def result(self) -> torch.Tensor:
+        _check_status(self.ws, "copy_if_lt_i32")
+        return self.out[: int(self.out_size.item())]
+
+
+def copy_if_lt(src: torch.Tensor, filter_value: int) -> torch.Tensor:
+    plan = CopyIfLt(src.numel(), src.device)
+    plan.launch(src, filter_value)
+    return plan.result()
+
+
+# ---------------------------------------------------------------------------------------------
+# dwarf 2: radix sort
+# ---------------------------------------------------------------------------------------------
+class RadixSort:
+    def __init__(self, n: int, radix_bits: int = 8, device="cuda"):
+        self.n, self.bits = n, radix_bits
+        self.ws_bytes = _capi.lib().dbhip_radix_sort_workspace_bytes(n, radix_bits)
+        self.ws = _ws(self.ws_bytes, device)
+        self.tmp = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+
+    def launch(self, keys: torch.Tensor, signed: bool = False) -> None:
+        """Sorts `keys` (int32 storage) in place; signed=False orders the bits as uint32."""
+        _need(keys, torch.int32, "keys")
+        if keys.numel() != self.n:
+            raise ValueError("size mismatch")
+        fn = _capi.lib().dbhip_radix_sort_i32 if signed else _capi.lib().dbhip_radix_sort_u32
+        _capi.check(fn(keys.data_ptr(), self.tmp.data_ptr(), self.n, self.bits, self.ws.data_ptr(), self.ws_bytes,
+                       _stream()), "radix_sort")
+
+
+def radix_sort_(keys: torch.Tensor, signed: bool = False, radix_bits: int = 8) -> torch.Tensor:
+    plan = RadixSort(keys.numel(), radix_bits, keys.device)
+    plan.launch(keys, signed)
+    _check_status(plan.ws, "radix_sort")
+    return keys
+
+
+# ---------------------------------------------------------------------------------------------
+# dwarf 3: group-by SUM
+# ---------------------------------------------------------------------------------------------
+class GroupBySum:
+    def __init__(self, n: int, groups: int, device="cuda"):
+        self.n, self.groups = n, groups
+        self.ws_bytes = _capi.lib().dbhip_groupby_sum_u32_workspace_bytes(n, groups)
+        self.ws = _ws(self.ws_bytes, device)
+        self.out = torch.empty(max(groups, 1), dtype=torch.int32, device=device)
+
+    def launch(self, keys: torch.Tensor, vals: torch.Tensor) -> None:
+        _need(keys, torch.int32, "keys")
+        _need(vals, torch.int32, "vals")
+        if keys.numel() != self.n or vals.numel() != self.n:
+            raise ValueError("size mismatch")
+        _capi.check(_capi.lib().dbhip_groupby_sum_u32(keys.data_ptr(), vals.data_ptr(), self.n, self.groups,
+                                                      self.out.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                      _stream()), "groupby_sum_u32")
+
+    def result(self) -> torch.Tensor:
+        _check_status(self.ws, "groupby_sum_u32")
+        return self.out[: self.groups]
+
+
+def groupby_sum(keys: torch.Tensor, vals: torch.Tensor, groups: int) -> torch.Tensor:
+    plan = GroupBySum(keys.numel(), groups, keys.device)
+    plan.launch(keys, vals)
+    return plan.result()
+
+
+# ---------------------------------------------------------------------------------------------
+# dwarf 4a: one-to-many hash join (JoinOmnisci semantics)
+# ---------------------------------------------------------------------------------------------
+class HashJoin:
+    def __init__(self, n_build: int, n_probe: int, device="cuda"):
+        self.nb, self.np = n_build, n_probe
+        self.ws_bytes = _capi.lib().dbhip_join_workspace_bytes(n_build)
+        self.ws = _ws(self.ws_bytes, device)
+        self.ids = torch.empty(max(n_build, 1), dtype=torch.int32, device=device)
+        self.pos = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+        self.cnt = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+
+    def build(self, build_keys: torch.Tensor) -> None:
+        _need(build_keys, torch.int32, "build_keys")
+        _capi.check(_capi.lib().dbhip_join_build_u32(build_keys.data_ptr(), self.nb, self.ids.data_ptr(),
+                                                     self.ws.data_ptr(), self.ws_bytes, _stream()), "join_build_u32")
+
+    def probe(self, probe_keys: torch.Tensor) -> None:
+        _need(probe_keys, torch.int32, "probe_keys")
+        _capi.check(_capi.lib().dbhip_join_probe_u32(probe_keys.data_ptr(), self.np, self.ws.data_ptr(),
+                                                     self.nb, self.pos.data_ptr(), self.cnt.data_ptr(), _stream()),
+                    "join_probe_u32")
+
+    def result(self):
+        _check_status(self.ws, "join")
+        return self.pos[: self.np], self.cnt[: self.np], self.ids[: self.nb]
+
+
+def hash_join(build_keys: torch.Tensor, probe_keys: torch.Tensor):
+    plan = HashJoin(build_keys.numel(), probe_keys.numel(), build_keys.device)
+    plan.build(build_keys)
+    plan.probe(probe_keys)
+    return plan.result()
+
+
+# ---------------------------------------------------------------------------------------------
+# dwarf 4b: unique-key payload join (Join semantics)
+# ---------------------------------------------------------------------------------------------
+class UniqueJoin:
+    def __init__(self, n_build: int, n_probe: int, device="cuda"):
+        self.nb, self.np = n_build, n_probe
+        self.ws_bytes = _capi.lib().dbhip_ujoin_workspace_bytes(n_build)
+        self.ws = _ws(self.ws_bytes, device)
+        self.out_key = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+        self.out_bval = torch.empty_like(self.out_key)
+        self.out_pval = torch.empty_like(self.out_key)
+
+    def build(self, keys: torch.Tensor, vals: torch.Tensor) -> None:
+        _need(keys, torch.int32, "build_keys")
+        _need(vals, torch.int32, "build_vals")
+        _capi.check(_capi.lib().dbhip_ujoin_build_u32(keys.data_ptr(), vals.data_ptr(), self.nb, self.ws.data_ptr(),
+                                                      self.ws_bytes, _stream()), "ujoin_build_u32")
+
+    def probe(self, keys: torch.Tensor, vals: torch.Tensor) -> None:
+        _need(keys, torch.int32, "probe_keys")
+        _need(vals, torch.int32, "probe_vals")
+        _capi.check(_capi.lib().dbhip_ujoin_probe_u32(keys.data_ptr(), vals.data_ptr(), self.np, self.ws.data_ptr(),
+                                                      self.nb, self.out_key.data_ptr(), self.out_bval.data_ptr(),
+                                                      self.out_pval.data_ptr(), _stream()), "ujoin_probe_u32")
+
+    def result(self):
+        _check_status(self.ws, "ujoin")
+        return self.out_key[: self.np], self.out_bval[: self.np], self.out_pval[: self.np]

@@ -1,0 +1,132 @@
+/*
+ * dbhip.h — C ABI of libdbhip.so, the MI355X (gfx950 / CDNA4) backend for dwarf_bench's
+ * data-parallel dwarf kernels.
+ *
+ * This is the drop-in seam behind the reference's Dwarf::run() hook (common/dwarf.hpp:15-16):
+ * every `...Hip` dwarf (dwarf_bench_amd/host/) and every test / bench driver calls exactly these
+ * entry points.  Plain pointers and sizes only: all data pointers are DEVICE pointers (hipMalloc'd
+ * or any allocator handing out device memory, e.g. torch), `stream` is a hipStream_t passed as
+ * void*, and every call is asynchronous on that stream.  Nothing here allocates, frees or
+ * synchronises: scratch memory is caller-provided through the `*_workspace_bytes` queries, so a
+ * call sequence can be captured into a hipGraph.
+ *
+ * Return value: 0 on success, a negative DBHIP_E* code for argument errors detected on the host,
+ * or a positive hipError_t if a launch failed.  Device-side failures (a bounded spin that timed
+ * out, an out-of-range group key, a full hash table) are reported through the status word that
+ * lives at the start of the workspace: read it back with dbhip_workspace_status() after the
+ * stream has been synchronised.
+ *
+ * Reference interfaces replaced (file:line in kurapov-peter/dwarf_bench):
+ *   dbhip_copy_if_lt_i32      scan/scan.cl:3-42 (kernel simple_two_pass_scan), scan/scan.cpp:107-128,
+ *                             common/dpcpp/dpl_wrapper/dpl_wrapper.hpp:27-33 (copy_if) <- scan/dplscan.cpp:43
+ *   dbhip_radix_sort_*        dpl_wrapper.hpp:35-39 (sort) <- sort/radix.cpp:34
+ *   dbhip_groupby_sum_u32     groupby/groupby.cpp:58-93 (hash_build + hash_build_check),
+ *                             common/dpcpp/hashtable.hpp:136-153, groupby/groupby_local.cpp:58-112
+ *   dbhip_join_*              common/dpcpp/omnisci_hashtable.hpp:58-261 <- join/join_omnisci.cpp:74-88
+ *   dbhip_ujoin_*             join/join.cpp:60-104, common/dpcpp/hashtable.hpp:5-93,
+ *                             common/dpcpp/hashfunctions.hpp:64-137 (MurmurHash3_x86_32)
+ *   dbhip_pjoin_*             no reference counterpart (multi-GPU radix-partitioned join)
+ *   dbhip_gen_*               common/common.hpp:31-40, common/common.cpp:7-20 (data generators)
+ */
+#ifndef DBHIP_H
+#define DBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBHIP_VERSION 1
+
+/* host-side argument errors (negative); positive values are hipError_t */
+#define DBHIP_OK 0
+#define DBHIP_EINVAL (-1)     /* null pointer / bad size / bad parameter */
+#define DBHIP_EWORKSPACE (-2) /* workspace too small or misaligned (needs 256-byte alignment) */
+#define DBHIP_ENODEVICE (-3)  /* no HIP device / not a gfx950-class device */
+
+/* device-side status word values (dbhip_workspace_status) */
+#define DBHIP_DEV_OK 0u
+#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* a look-back wait gave up: result is invalid */
+#define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count */
+#define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
+
+typedef void *dbhip_stream_t; /* hipStream_t */
+
+/* ---- library / device ------------------------------------------------------------------- */
+int dbhip_version(void);
+/* Fills name (<=len bytes), compute units and wavefront size of HIP device `device`. */
+int dbhip_device_info(int device, char *name, size_t len, int *compute_units, int *wave_size);
+/* Asynchronously copies the status word of a workspace to *host_status (pinned or pageable),
+ * then synchronises `stream`.  Convenience for hosts that have no other D2H path. */
+int dbhip_workspace_status(const void *workspace, uint32_t *host_status, dbhip_stream_t stream);
+
+/* ---- deterministic synthetic data (counter-based; oracle/dbo_gen.c is the CPU twin) ---------
+ * element i of the logical column = lo + mix64(seed, first_index + i) % (hi - lo + 1)            */
+int dbhip_gen_uniform_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t first_index,
+                          uint32_t lo, uint32_t hi, dbhip_stream_t stream);
+/* unique ascending keys in [0, 10*N): element i = 10*(first_index+i) + mix64(seed, first_index+i) % 10
+ * (same shape as helpers::make_unique_random, common/common.cpp:7-20) */
+int dbhip_gen_unique_sorted_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t first_index,
+                                dbhip_stream_t stream);
+
+/* ---- dwarf 1: scan / stream compaction --------------------------------------------------------
+ * out[0..*out_size) = [x in src : x < filter_value] in source order (stable), *out_size = count.
+ * One pass over src (decoupled look-back); `out` needs room for n elements in the worst case.
+ * out_size is a DEVICE pointer to one uint64.                                                    */
+size_t dbhip_copy_if_lt_i32_workspace_bytes(size_t n);
+int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,
+                         uint64_t *out_size, void *workspace, size_t workspace_bytes,
+                         dbhip_stream_t stream);
+
+/* ---- dwarf 2: LSD radix sort ---------------------------------------------------------------
+ * Ascending sort of n 32-bit keys.  keys is sorted IN PLACE; tmp is an n-element ping-pong buffer.
+ * radix_bits in {4, 8}: digit width of every pass (4 = the configuration named in BASELINE.json,
+ * 8 = the tuned variant).  Passes whose digit is constant over the whole input are skipped.      */
+size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits);
+int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits, void *workspace,
+                         size_t workspace_bytes, dbhip_stream_t stream);
+/* signed order (the reference sorts `int`, sort/radix.cpp:8-12) */
+int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits, void *workspace,
+                         size_t workspace_bytes, dbhip_stream_t stream);
+
+/* ---- dwarf 3: group-by hash aggregate, SUM ------------------------------------------------------
+ * out[g] = sum of vals[i] over rows with keys[i] == g (uint32 wrap-around), g in [0, groups).
+ * Keys must be < groups (the reference's dense output[key] contract, groupby/groupby.cpp:88-91);
+ * a larger key sets DBHIP_DEV_KEY_RANGE and is ignored.                                           */
+size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t groups);
+int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups,
+                          uint32_t *out, void *workspace, size_t workspace_bytes,
+                          dbhip_stream_t stream);
+
+/* ---- dwarf 4a: one-to-many hash join (JoinOmnisci semantics) -----------------------------------
+ * Build: hash table over the DISTINCT build keys, per-key match count, exclusive scan -> position,
+ * ids[pos .. pos+count) = build row indices carrying that key (order inside a key's range is not
+ * defined, as in the reference).  Probe: per probe row i, out_count[i] = number of build rows with
+ * the same key and out_pos[i] = offset of their ids (0/0 on a miss).
+ * 0xFFFFFFFF is the empty-slot sentinel and must not occur as a key
+ * (join/join_omnisci.cpp:52).  The table lives in the workspace between build and probe; the
+ * probe takes n_build again because the table geometry is a pure function of it.               */
+size_t dbhip_join_workspace_bytes(size_t n_build);
+int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids, void *workspace,
+                         size_t workspace_bytes, dbhip_stream_t stream);
+int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void *workspace,
+                         size_t n_build, uint32_t *out_pos, uint32_t *out_count,
+                         dbhip_stream_t stream);
+
+/* ---- dwarf 4b: unique-key join carrying payloads (Join semantics, join/join.cpp:60-104) ---------
+ * Build keys are unique.  For probe row i: on a hit out_key[i] = key, out_build_val[i] = payload of
+ * the build row, out_probe_val[i] = probe payload; on a miss all three are left at 0xFFFFFFFF
+ * (the caller's sentinel fill, join/join.cpp:41-43 — this call writes the sentinel itself).       */
+size_t dbhip_ujoin_workspace_bytes(size_t n_build);
+int dbhip_ujoin_build_u32(const uint32_t *build_keys, const uint32_t *build_vals, size_t n_build,
+                          void *workspace, size_t workspace_bytes, dbhip_stream_t stream);
+int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t *probe_vals, size_t n_probe,
+                          const void *workspace, size_t n_build, uint32_t *out_key,
+                          uint32_t *out_build_val, uint32_t *out_probe_val, dbhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBHIP_H */

@@ -1,0 +1,73 @@
+"""Parity of the HIP group-by with expected_GroupBy (groupby/groupby.cpp:8-19) through the C ABI."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(keys_h, vals_h, groups):
+    from dwarf_bench_amd import ops
+    k = torch.from_numpy(np.ascontiguousarray(keys_h, dtype=np.uint32).view(np.int32)).cuda()
+    v = torch.from_numpy(np.ascontiguousarray(vals_h, dtype=np.uint32).view(np.int32)).cuda()
+    return ops.groupby_sum(k, v, groups).cpu().numpy().view(np.uint32)
+
+
+def test_reference_fixture(golden_dir):
+    k = json.loads((golden_dir / "reference_kats.json").read_text())["groupby_fixture"]
+    assert _run(k["keys"], k["vals"], k["groups"]).tolist() == k["expected"]
+
+
+@pytest.mark.parametrize("groups", [1, 2, 20, 64, 257, 4096, 32768, 32769, 65536, 100000])
+@pytest.mark.parametrize("n", [0, 1, 5, 128, 4096, 100003, 1 << 20])
+def test_groupby_matches_oracle(n, groups):
+    keys = po.gen_uniform_u32(n, 42, 0, groups - 1)
+    vals = po.gen_uniform_u32(n, 43, 1, 10000)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
+def test_wraparound_sums():
+    n, groups = 50000, 7
+    keys = po.gen_uniform_u32(n, 1, 0, groups - 1)
+    vals = po.gen_uniform_u32(n, 2, 2**31, 2**32 - 1)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
+def test_skewed_keys():
+    n, groups = 1 << 18, 65536
+    keys = np.zeros(n, np.uint32)
+    keys[::3] = 65535
+    keys[1::1000] = 32768
+    vals = po.gen_uniform_u32(n, 5, 1, 10000)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
+def test_out_of_range_key_is_flagged():
+    from dwarf_bench_amd import ops, _capi
+    k = torch.tensor([0, 1, 9, 2], dtype=torch.int32).cuda()
+    v = torch.ones(4, dtype=torch.int32).cuda()
+    plan = ops.GroupBySum(4, 4)
+    plan.launch(k, v)
+    assert ops.workspace_status(plan.ws) == ops.DEV_KEY_RANGE
+    with pytest.raises(_capi.DbhipError):
+        plan.result()
+
+
+def test_baseline_config_2_26_rows_2_16_groups():
+    """BASELINE configs[2].  Cross-checked with torch (independent) at full size and the oracle on a sample."""
+    from dwarf_bench_amd import ops
+    n, groups = 1 << 26, 1 << 16
+    keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+    vals = ops.gen_uniform_u32(n, 43, 1, 10000)
+    got = ops.groupby_sum(keys, vals, groups)
+    exp = torch.zeros(groups, dtype=torch.int64, device="cuda").index_add_(0, keys.to(torch.int64), vals.to(torch.int64))
+    assert torch.equal(got.to(torch.int64) & 0xFFFFFFFF, exp & 0xFFFFFFFF)
+    assert int(got.to(torch.int64).sum().item()) == int(vals.to(torch.int64).sum().item())  # checksum of checksums
+    m = 1 << 21
+    kh, vh = keys[:m].cpu().numpy().view(np.uint32), vals[:m].cpu().numpy().view(np.uint32)
+    assert np.array_equal(ops.groupby_sum(keys[:m], vals[:m], groups).cpu().numpy().view(np.uint32),
+                          po.groupby_sum(kh, vh, groups))

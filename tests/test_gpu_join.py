@@ -1,0 +1,112 @@
+"""Parity of the HIP hash joins with the oracle restatements (omnisci_hashtable.hpp / join.cpp) through the C ABI.
+Canonical forms per SURVEY 8(a): per-probe-row count identical, id lists identical after sorting inside a bucket;
+payload join compared as a multiset of rows."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()
+
+
+def _join(build, probe):
+    from dwarf_bench_amd import ops
+    pos, cnt, ids = ops.hash_join(_dev(build), _dev(probe))
+    return (pos.cpu().numpy().view(np.uint32), cnt.cpu().numpy().view(np.uint32), ids.cpu().numpy().view(np.uint32))
+
+
+def _check_against_bruteforce(build, probe):
+    pos, cnt, ids = _join(build, probe)
+    bc, off, bids = po.join_bruteforce(build, probe)
+    assert np.array_equal(cnt.astype(np.uint64), bc)
+    for i in range(len(probe)):
+        got = np.sort(ids[pos[i]: pos[i] + cnt[i]])
+        assert np.array_equal(got.astype(np.uint64), bids[int(off[i]): int(off[i + 1])]), i
+    # ids is a permutation of the build rows, grouped by key
+    assert np.array_equal(np.sort(ids), np.arange(len(build), dtype=np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 128, 256, 512, 1024, 2048, 4096])
+def test_join_reference_distribution(n):
+    """join/join_omnisci.cpp:53-58: both sides uniform in [1,10000] (heavy duplicates)."""
+    _check_against_bruteforce(po.gen_uniform_u32(n, 42, 1, 10000), po.gen_uniform_u32(n, 43, 1, 10000))
+
+
+def test_join_ragged_sizes_and_misses():
+    _check_against_bruteforce(po.gen_uniform_u32(3000, 1, 1, 500), po.gen_uniform_u32(777, 2, 400, 900))
+    _check_against_bruteforce(np.array([5, 5, 5, 5], np.uint32), np.array([5, 6], np.uint32))
+    _check_against_bruteforce(np.array([0, 4294967294], np.uint32), np.array([4294967294, 0, 1], np.uint32))
+
+
+def test_join_empty_sides():
+    pos, cnt, ids = _join(np.array([], np.uint32), np.array([1, 2, 3], np.uint32))
+    assert cnt.tolist() == [0, 0, 0] and pos.tolist() == [0, 0, 0]
+    pos, cnt, ids = _join(np.array([1, 2, 3], np.uint32), np.array([], np.uint32))
+    assert len(cnt) == 0 and sorted(ids.tolist()) == [0, 1, 2]
+
+
+def test_join_vs_oracle_table_large():
+    """2^20 x 2^20 with the OmniSci restatement (multi-threaded oracle) — counts + sorted buckets on a sample."""
+    n = 1 << 20
+    build = po.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = po.gen_uniform_u32(n, 43, 0, n - 1)
+    pos, cnt, ids = _join(build, probe)
+    opos, ocnt, oids = po.join_omnisci(build, probe, threads=8)
+    assert np.array_equal(cnt.astype(np.uint64), ocnt)
+    assert np.array_equal(cnt.astype(np.uint64), po.join_counts_fast(build, probe))
+    for i in range(0, n, 4099):
+        a = np.sort(ids[pos[i]: pos[i] + cnt[i]]).astype(np.uint64)
+        b = np.sort(oids[int(opos[i]): int(opos[i] + ocnt[i])])
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    assert np.all(build[ids[pos[cnt > 0]]] == probe[cnt > 0])
+
+
+def test_join_baseline_config_2_26_properties():
+    """BASELINE configs[3]: 2^26 x 2^26.  Size-independent properties, checked on the device."""
+    from dwarf_bench_amd import ops
+    n = 1 << 26
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    pos, cnt, ids = ops.hash_join(build, probe)
+    # ids is a permutation of the build rows
+    assert int(ids.to(torch.int64).sum().item()) == n * (n - 1) // 2
+    assert torch.equal(torch.sort(ids).values, torch.arange(n, dtype=torch.int32, device="cuda"))
+    # every reported match really matches, on first and last id of each bucket
+    hit = cnt > 0
+    p = pos[hit].to(torch.int64)
+    c = cnt[hit].to(torch.int64)
+    assert torch.equal(build[ids[p].to(torch.int64)], probe[hit])
+    assert torch.equal(build[ids[p + c - 1].to(torch.int64)], probe[hit])
+    # total matches == sum over distinct keys of cnt_build * cnt_probe (independent torch computation)
+    ub, cb = torch.unique(build, return_counts=True)
+    up, cp = torch.unique(probe, return_counts=True)
+    idx = torch.searchsorted(ub, up).clamp_(max=ub.numel() - 1)
+    m = ub[idx] == up
+    assert int(cnt.to(torch.int64).sum().item()) == int((cb[idx][m] * cp[m]).sum().item())
+
+
+def test_ujoin_reference_fixture_shape(golden_dir):
+    """unique-key payload join vs seq_join (join_helpers.hpp:86-104) as a multiset of rows (join.cpp:133)."""
+    from dwarf_bench_amd import ops
+    for n in (1, 128, 1024, 4096, 50000):
+        ak, bk = po.gen_unique_sorted_u32(n, 11), po.gen_unique_sorted_u32(n, 12)
+        av, bv = po.gen_uniform_u32(n, 13, 0, 10**6), po.gen_uniform_u32(n, 14, 0, 10**6)
+        plan = ops.UniqueJoin(n, n)
+        plan.build(_dev(ak), _dev(av))
+        plan.probe(_dev(bk), _dev(bv))
+        ok, o1, o2 = (t.cpu().numpy().view(np.uint32) for t in plan.result())
+        ek, e1, e2 = po.ujoin(ak, av, bk, bv)
+        assert np.array_equal(ok, ek) and np.array_equal(o1, e1) and np.array_equal(o2, e2)
+        if n <= 4096:
+            hit = ok != 0xFFFFFFFF
+            sk, s1, s2 = po.seq_join(ak, av, bk, bv)
+            assert sorted(zip(ok[hit].tolist(), o1[hit].tolist(), o2[hit].tolist())) == \
+                sorted(zip(sk.tolist(), s1.tolist(), s2.tolist()))

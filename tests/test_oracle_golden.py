@@ -1,0 +1,179 @@
+"""Pins the CPU oracle (oracle/dbo.c) against
+  (a) the known-answer vectors the reference's own tests hold (tests/golden/reference_kats.json), and
+  (b) vectors produced by the reference's own code compiled here (tests/golden/ref_vectors.json, generated
+      by tests/golden/make_golden.py through oracle/_ref).
+CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+
+@pytest.fixture(scope="module")
+def kats(golden_dir):
+    return json.loads((golden_dir / "reference_kats.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def refv(golden_dir):
+    return json.loads((golden_dir / "ref_vectors.json").read_text())
+
+
+def test_prefix_sum_kat(kats):
+    k = kats["scan_prefix_sum"]
+    assert po.prefix_sum_exclusive(k["in"]).tolist() == k["expected"]
+
+
+def test_groupby_fixture(kats):
+    k = kats["groupby_fixture"]
+    assert po.groupby_sum(k["keys"], k["vals"], k["groups"]).tolist() == k["expected"]
+    # the reference test runs the fixture through NonOwningHashTableNonBitmask + PolynomialHasher(50)
+    for p in (2, 7, 31, 43):
+        assert po.groupby_hash(k["keys"], k["vals"], k["groups"], table_size=50, p=p).tolist() == k["expected"]
+        assert po.groupby_hash(k["keys"], k["vals"], k["groups"], table_size=50, p=p, threads=4).tolist() == k["expected"]
+    assert po.groupby_local(k["keys"], k["vals"], k["groups"], executors=8).tolist() == k["expected"]
+
+
+def test_seq_join_fixture(kats):
+    k = kats["seq_join_fixture"]
+    ok, o1, o2 = po.seq_join(k["keys_a"], k["vals_a"], k["keys_b"], k["vals_b"])
+    rows = np.stack([ok, o1, o2], 1).tolist()
+    assert len(rows) == 8
+    assert rows == k["expected_rows"]
+
+
+def test_bitmask_table_build(kats):
+    k = kats["bitmask_table_build"]
+    t = po.BitmaskTable(k["size"], hash_kind=0)
+    for key, val in k["inserts"]:
+        t.insert(key, val)
+    for v in k["double_insert_vals"]:
+        t.insert(k["double_insert_key"], v)
+    data = t.data()
+    for slot, val in k["expected_data"].items():
+        assert data[int(slot)] == val
+    assert data[10] + data[11] == k["expected_sum_slots_10_11"]
+
+
+def test_bitmask_table_probe_and_has(kats):
+    k = kats["bitmask_table_probe"]
+    t = po.BitmaskTable(k["size"], hash_kind=0)
+    for key, val in k["inserts"]:
+        t.insert(key, val)
+    assert [t.at(q)[0] for q in k["queries"]] == k["expected_vals"]
+    k = kats["bitmask_table_has"]
+    t = po.BitmaskTable(k["size"], hash_kind=0)
+    for key, val in k["inserts"]:
+        t.insert(key, val)
+    assert [int(t.at(q)[1]) for q in k["queries"]] == k["expected"]
+
+
+def test_bitmask_big_build():
+    # tests/hash_table_tests.cpp:183-228: 500 unique keys, 500 slots, every payload lands in its own slot
+    t = po.BitmaskTable(500, hash_kind=0)
+    for i in range(500):
+        t.insert(i, i)
+    assert len(set(t.data().tolist())) == 500
+
+
+def test_murmur3_kat(kats):
+    k = kats["murmur3_kat"]
+    assert po.murmur3_x86_32(k["key"], k["seed"]) % k["sz"] == k["expected"]
+
+
+def test_hashers_vs_reference_code(refv):
+    for case in refv["murmur3"]:
+        got = [po.murmur3_x86_32(k, case["seed"]) % case["sz"] for k in case["keys"]]
+        assert got == case["hash"]
+    for case in refv["simple"]:
+        assert [po.simple_hash(k, case["sz"]) for k in case["keys"]] == case["hash"]
+    for case in refv["polynomial"]:
+        assert [po.polynomial_hash(k, case["p"], case["sz"]) for k in case["keys"]] == case["hash"]
+
+
+def test_seq_join_vs_reference_code(refv):
+    for case in refv["seq_join"]:
+        ok, o1, o2 = po.seq_join(case["a_keys"], case["a_vals"], case["b_keys"], case["b_vals"])
+        assert np.stack([ok, o1, o2], 1).tolist() == case["rows"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1024, 1031, 4096])
+def test_two_pass_scan_restatement(n):
+    """scan.cl restated == std::copy_if whenever n % tnum == 0; the reference drops the tail otherwise."""
+    src = po.gen_uniform_u32(n, seed=5, lo=1, hi=10000).astype(np.int32)
+    for filt in (5, 5001):
+        exp = po.copy_if_lt(src, filt)
+        assert exp.tolist() == src[src < filt].tolist()
+        out, osz, prefix = po.two_pass_scan(src, filt, tnum=8)
+        head = n - n % 8
+        assert out.tolist() == src[:head][src[:head] < filt].tolist()
+        assert prefix[-1] == osz
+        got, k = po.chunked_scan(src, filt, threads=4)
+        assert got.tolist() == exp.tolist()
+
+
+def test_dwarf_test_sizes_property(kats):
+    """tests/dwarf_tests/dwarf_tests.cpp:44-58: sizes 128..4096 — oracle variants agree with each other."""
+    cfg = kats["dwarf_test_sizes"]
+    for n in cfg["sizes"]:
+        g = cfg["groups_count"]
+        keys = po.gen_uniform_u32(n, 1, 0, g - 1)
+        vals = po.gen_uniform_u32(n, 2, 1, 10000)
+        exp = po.groupby_sum(keys, vals, g)
+        assert po.groupby_hash(keys, vals, g, p=31).tolist() == exp.tolist()
+        assert po.groupby_local(keys, vals, g, cfg["executors"]).tolist() == exp.tolist()
+        a = po.gen_uniform_u32(n, 3, 1, 10000)
+        b = po.gen_uniform_u32(n, 4, 1, 10000)
+        pos, cnt, ids = po.join_omnisci(a, b, threads=2)
+        bc, off, bids = po.join_bruteforce(a, b)
+        assert cnt.tolist() == bc.tolist()
+        assert po.join_counts_fast(a, b).tolist() == bc.tolist()
+        for i in range(0, n, 97):
+            assert sorted(ids[int(pos[i]): int(pos[i] + cnt[i])].tolist()) == bids[int(off[i]): int(off[i + 1])].tolist()
+        s = po.gen_uniform_u32(n, 9, 0, 2**32 - 1)
+        assert po.sort_u32(s).tolist() == np.sort(s).tolist()
+        tmp = np.empty_like(s)
+        s2 = s.copy()
+        po.radix_sort_u32_mt(s2, tmp, threads=3)
+        assert s2.tolist() == np.sort(s).tolist()
+        assert po.sort_i32(s.view(np.int32)).tolist() == np.sort(s.view(np.int32)).tolist()
+
+
+def test_ujoin_matches_seq_join():
+    n = 512
+    ak = po.gen_unique_sorted_u32(n, 11)
+    bk = po.gen_unique_sorted_u32(n, 12)
+    av = po.gen_uniform_u32(n, 13, 0, 10**6)
+    bv = po.gen_uniform_u32(n, 14, 0, 10**6)
+    ok, o1, o2 = po.ujoin(ak, av, bk, bv, seed=42)
+    hit = ok != 0xFFFFFFFF
+    got = sorted(zip(ok[hit].tolist(), o1[hit].tolist(), o2[hit].tolist()))
+    ek, e1, e2 = po.seq_join(ak, av, bk, bv)
+    assert got == sorted(zip(ek.tolist(), e1.tolist(), e2.tolist()))
+    assert 0 < len(got) < n
+
+
+def test_generators_are_counter_based():
+    a = po.gen_uniform_u32(1000, 42, 1, 10000)
+    b = po.gen_uniform_u32(600, 42, 1, 10000, first_index=400)
+    assert a[400:].tolist() == b.tolist()
+    assert a.min() >= 1 and a.max() <= 10000
+    u = po.gen_unique_sorted_u32(1000, 3)
+    assert np.all(np.diff(u.astype(np.int64)) > 0) and u.max() < 10000
+    assert po.mix64(42, 0) == 0x9E3779B97F4A7C15 * 1 + 0 or True  # value pinned below
+    assert [po.mix64(42, i) for i in range(3)] == GOLDEN_MIX64
+
+
+GOLDEN_MIX64 = None  # filled at import time from the committed fixture
+
+
+def _load_mix():
+    import pathlib
+    global GOLDEN_MIX64
+    p = pathlib.Path(__file__).parent / "golden" / "mix64.json"
+    GOLDEN_MIX64 = json.loads(p.read_text())["mix64_seed42_i0_2"]
+
+
+_load_mix()
