@@ -59,7 +59,8 @@ def build_hip(force: bool = False) -> Path:
             o = odir / (s.stem + ".o")
             if force or _stale(o, [s] + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "dbhip.h"]):
                 _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-                      "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
+                      "-Wall", "-Wno-unused-function"] + os.environ.get("DBHIP_EXTRA_FLAGS", "").split()
+                     + ["-c", s, "-o", o])
             objs.append(o)
         _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
     return out

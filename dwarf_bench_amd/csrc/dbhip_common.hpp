@@ -56,6 +56,14 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it
+// would wait for every global load the wave has in flight — exactly the prefetch a software
+// pipeline wants to keep flying across the barrier.  Register uses of loaded values are still
+// guarded by the compiler's own counted waits.
+__device__ __forceinline__ void wg_barrier_lds_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // number of set bits of `mask` in lanes below the calling lane
 __device__ __forceinline__ unsigned mbcnt(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),

@@ -33,7 +33,7 @@ struct JoinHeader {
 static_assert(sizeof(JoinHeader) == kWsHeader, "workspace header size");
 
 inline size_t join_capacity(size_t n_build) {
-  size_t cap = 1024;
+  size_t cap = kScanTileElems;  // at least one full scan tile
   while (cap < 2 * n_build) cap <<= 1;  // load factor <= 0.5 (reference: ht_size = 2 * distinct)
   return cap;
 }
