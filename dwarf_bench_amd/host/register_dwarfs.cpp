@@ -1,0 +1,17 @@
+// register_dwarfs.cpp — populate_registry() (reference: register_dwarfs.cpp:20-56).  The reference
+// registers its dwarfs under EXPERIMENTAL / DPCPP_ENABLED / CUDA_ENABLED guards; this build has one
+// guard, HIP_ENABLED, and registers the hand-written gfx950 dwarfs.
+#include "dwarf_api.hpp"
+#include "hip_dwarfs.hpp"
+
+void populate_registry() {
+  Registry *registry = Registry::instance();
+#ifdef HIP_ENABLED
+  registry->registerd(new TwoPassScanHip());
+  registry->registerd(new DPLScanHip());
+  registry->registerd(new RadixHip());
+  registry->registerd(new GroupByHip());
+  registry->registerd(new JoinOmnisciHip());
+  registry->registerd(new JoinHip());
+#endif
+}

@@ -1,0 +1,67 @@
+"""End-to-end through the C++ host layer on the GPU: the `dwarf_bench` CLI and the `dbench` library example.
+Mirrors the reference's dwarf tests (tests/dwarf_tests/dwarf_tests.cpp:12-88): every dwarf x sizes
+{128..4096} x 10 iterations, every result valid (an invalid result prints "ncorrect results" on stderr)."""
+import csv
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+LIB = Path(__file__).resolve().parents[1] / "dwarf_bench_amd" / "_lib"
+SIZES = ["128", "256", "512", "1024", "2048", "4096"]
+
+
+def _run(args, **kw):
+    return subprocess.run([str(LIB / "dwarf_bench")] + args, capture_output=True, text=True, timeout=300, **kw)
+
+
+@pytest.mark.parametrize("dwarf", ["TwoPassScanHip", "DPLScanHip", "RadixHip", "JoinOmnisciHip", "JoinHip"])
+def test_dwarf_suite(dwarf):
+    r = _run([dwarf, "--device=hip", "--iterations", "10", "--input_size"] + SIZES)
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 10 * len(SIZES)
+    if "Join" in dwarf:
+        assert r.stdout.count("Build time:") == 10 * len(SIZES)
+
+
+def test_groupby_suite_with_reference_test_options():
+    """tests/dwarf_tests/utils.cpp:39-47: groups_count=64, executors=1024"""
+    r = _run(["GroupByHip", "--device=hip", "--iterations", "10", "--groups_count", "64", "--executors", "1024",
+              "--input_size"] + SIZES)
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 10 * len(SIZES)
+
+
+def test_baseline_plumbing_config_csv(tmp_path):
+    """BASELINE configs[0] on the HIP device: TwoPassScan --input_size=1024 --iterations=9 -> 9 valid rows,
+    reference CSV schema (common/result.cpp:59-91), appended on a second run."""
+    rep = tmp_path / "report.csv"
+    for _ in range(2):
+        r = _run(["TwoPassScanHip", "--device=hip", "--input_size=1024", "--iterations=9", f"--report_path={rep}"])
+        assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
+    rows = list(csv.reader(rep.open()))
+    assert rows[0] == ["device_type", "buf_size_bytes", "host_time_ms", "kernel_time_ms"]
+    assert len(rows) == 1 + 18
+    for row in rows[1:]:
+        assert row[0] == "HIP" and row[1] == "4096" and float(row[2]) >= 0 and float(row[3]) >= 0
+
+
+def test_large_sizes_through_cli():
+    r = _run(["TwoPassScanHip", "--device=hip", "--iterations", "3", "--input_size", "16777216"])
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    r = _run(["RadixHip", "--device=hip", "--iterations", "3", "--input_size", "1000003"])
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    r = _run(["GroupByHip", "--device=hip", "--iterations", "3", "--groups_count", "65536", "--input_size", "4194304"])
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+
+
+def test_library_usage_example():
+    """the README / example/bench_usage flow through DwarfBench::makeMeasurements with DeviceType::HIP"""
+    r = subprocess.run([str(LIB / "bench_usage")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if "RESULT:" in l]
+    assert len(lines) == 4 * 10  # 4 dwarfs x 10 iterations
+    assert all(l.split()[3] == "1024" for l in lines)
+    assert "ncorrect results" not in r.stderr
