@@ -162,6 +162,49 @@ def bench_join(steps, warmup, log2n=26):
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 
+def bench_pjoin(steps, warmup, log2_total=30, dist=None):
+    """Radix-partitioned hash join of 2^log2_total x 2^log2_total rows over all ranks (strong scaling: the total
+    is fixed, every rank holds a contiguous 1/P shard of both key columns, generated in place)."""
+    import torch
+    from dwarf_bench_amd import ops, pjoin
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    total = 1 << log2_total
+    per = total // world
+    lo = rank * per
+    n_local = total - lo if rank == world - 1 else per
+    build = ops.gen_uniform_u32(n_local, 42, 0, total - 1, first_index=lo)
+    probe = ops.gen_uniform_u32(n_local, 43, 0, total - 1, first_index=lo)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(warmup):
+        res = pjoin.partitioned_join(build, probe, lo, lo)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pjoin.partitioned_join(build, probe, lo, lo)
+    sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    if dist is not None:
+        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    matches = int(res.cnt.to(torch.int64).sum().item())
+    stats = torch.tensor([matches, res.sent_rows, res.recv_build_rows + res.recv_probe_rows], dtype=torch.int64, device="cuda")
+    mx = stats.clone()
+    if dist is not None:
+        dist.all_reduce(stats)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return {"rows": 2 * total, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": int(stats[0]),
+            "rows_exchanged": int(stats[1]), "max_over_mean_rows_per_rank": float(mx[2]) * world / max(int(stats[2]), 1),
+            "workload": f"radix-partitioned HashJoin 2^{log2_total} x 2^{log2_total} uint32 keys over {world} GPU(s)"}
+
+
 def cpu_baseline_scan(src_dev, filt, budget_s=12.0):
     """The oracle's chunked scan (scan.cl restated, T chunks on T threads) on a bounded sample of the same column."""
     import numpy as np
@@ -214,7 +257,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- headline: scan 2^28 on every rank (replicas only for N > 1: the scan does not shard)
+    if n_gpus > 1:
+        # ---- MULTI-GPU: the one path of the hot path that shards (BASELINE north_star): the hash join,
+        # radix-partitioned across the ranks with an RCCL all-to-all bucket exchange.  Total work is fixed.
+        pj = bench_pjoin(max(1, min(args.steps, 5)), max(1, min(args.warmup, 2)), 30, dist)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "Mrows/s, radix-partitioned hash join 2^30 x 2^30 (build+probe rows / s, all GPUs)",
+                "value": pj["mrows_per_s"], "unit": "Mrows/s", "n_gpus": n_gpus, "steps": max(1, min(args.steps, 5)),
+                "warmup": max(1, min(args.warmup, 2)), "ms_per_step": pj["ms_per_step"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "uint32", "data": "synthetic",
+                "config": {"workload": pj["workload"], "rows": pj["rows"], "parallelism": f"hash-partitioned over {n_gpus} ranks, "
+                           "all_to_all bucket exchange (RCCL over xGMI), local open-addressing join per rank",
+                           "single_gpu_reference": "the N=1 line of this bench reports the same join on one GPU under dwarfs.pjoin_p1"},
+                "roofline": None, "cpu_baseline": None,
+                "pjoin": {k: v for k, v in pj.items() if k != "workload"},
+            }))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---- headline: scan 2^28 (BASELINE.json's metric configuration)
     barrier()
     scan = bench_scan(args.steps, args.warmup)
     barrier()
@@ -266,6 +329,9 @@ def main():
             dwarfs["groupby"] = bench_groupby(k, 2)
         if args.dwarf in ("all", "join"):
             dwarfs["join"] = bench_join(max(3, k // 2), 2)
+            torch.cuda.empty_cache()
+            pj = bench_pjoin(2, 1, 30, None)  # the single-GPU reference point of the multi-GPU line
+            dwarfs["pjoin_p1"] = {k2: v for k2, v in pj.items()}
         out["dwarfs"] = dwarfs
 
     if rank == 0:

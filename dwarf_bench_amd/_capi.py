@@ -31,6 +31,9 @@ SIGNATURES = {
     "dbhip_ujoin_workspace_bytes": (_sz, [_sz]),
     "dbhip_ujoin_build_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "dbhip_ujoin_probe_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dbhip_pjoin_partition_workspace_bytes": (_sz, [_sz, _u32]),
+    "dbhip_pjoin_partition_u32": (_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dbhip_gather_u32": (_int, [_vp, _vp, _sz, _vp, _vp]),
 }
 
 _lib = None

@@ -222,3 +222,31 @@ class UniqueJoin:
     def result(self):
         _check_status(self.ws, "ujoin")
         return self.out_key[: self.np], self.out_bval[: self.np], self.out_pval[: self.np]
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU partitioned join: device pieces (the exchange lives in pjoin.py)
+# ---------------------------------------------------------------------------------------------
+def partition_by_hash(keys: torch.Tensor, first_row_id: int, parts: int):
+    """-> (keys bucket-major, global row ids bucket-major, counts[parts] int64 on the device)"""
+    _need(keys, torch.int32, "keys")
+    n = keys.numel()
+    lib = _capi.lib()
+    ws_bytes = lib.dbhip_pjoin_partition_workspace_bytes(n, parts)
+    ws = _ws(ws_bytes, keys.device)
+    out_keys = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
+    out_rids = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
+    counts = torch.zeros(parts, dtype=torch.int64, device=keys.device)
+    _capi.check(lib.dbhip_pjoin_partition_u32(keys.data_ptr(), n, first_row_id, parts, out_keys.data_ptr(),
+                                              out_rids.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws_bytes,
+                                              _stream()), "pjoin_partition_u32")
+    return out_keys[:n], out_rids[:n], counts
+
+
+def gather_u32(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _need(table, torch.int32, "table")
+    _need(idx, torch.int32, "idx")
+    out = torch.empty(max(idx.numel(), 1), dtype=torch.int32, device=idx.device)
+    _capi.check(_capi.lib().dbhip_gather_u32(table.data_ptr(), idx.data_ptr(), idx.numel(), out.data_ptr(), _stream()),
+                "gather_u32")
+    return out[: idx.numel()]

@@ -126,6 +126,21 @@ int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t *probe_vals
                           const void *workspace, size_t n_build, uint32_t *out_key,
                           uint32_t *out_build_val, uint32_t *out_probe_val, dbhip_stream_t stream);
 
+/* ---- multi-GPU radix-partitioned join: device pieces (no reference counterpart) ---------
+ * Partition a local column shard into `parts` (1..256) destination buckets by the mixed hash of
+ * the key: out_keys / out_row_ids are bucket-major (bucket d occupies
+ * [sum(out_counts[0..d)), +out_counts[d])), out_row_ids[i] = first_row_id + local index of the key
+ * (global row ids must fit 32 bits), out_counts is a DEVICE array of `parts` uint64.  The exchange
+ * between GPUs is the host's job (RCCL all-to-all); the local join on the received pairs is
+ * dbhip_join_build_u32 / dbhip_join_probe_u32, and dbhip_gather_u32 (out[i] = table[idx[i]]) turns
+ * its build-row indices into global row ids.                                                      */
+size_t dbhip_pjoin_partition_workspace_bytes(size_t n, uint32_t parts);
+int dbhip_pjoin_partition_u32(const uint32_t *keys, size_t n, uint64_t first_row_id, uint32_t parts,
+                              uint32_t *out_keys, uint32_t *out_row_ids, uint64_t *out_counts,
+                              void *workspace, size_t workspace_bytes, dbhip_stream_t stream);
+int dbhip_gather_u32(const uint32_t *table, const uint32_t *idx, size_t n, uint32_t *out,
+                     dbhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

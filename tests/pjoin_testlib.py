@@ -1,0 +1,59 @@
+"""Test-only helpers for the partitioned join: a numpy/oracle backend for CPU rehearsals of the exchange, the
+hash the device partitioner uses restated in numpy, and the global checker.  Never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import pyoracle as po
+
+
+def fmix32(k: np.ndarray) -> np.ndarray:
+    h = k.astype(np.uint64)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85ebca6b)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xc2b2ae35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def dest_of(keys: np.ndarray, parts: int) -> np.ndarray:
+    """(fmix32(key) * parts) >> 32, as pj_dest in csrc/pjoin.hip"""
+    return ((fmix32(keys) * np.uint64(parts)) >> np.uint64(32)).astype(np.int64)
+
+
+class OracleBackend:
+    """CPU stand-in for HipBackend: same contracts, numpy + the oracle's OmniSci restatement."""
+
+    def partition(self, keys, first_row_id, parts):
+        k = keys.numpy().view(np.uint32)
+        d = dest_of(k, parts)
+        order = np.argsort(d, kind="stable")
+        counts = np.bincount(d, minlength=parts).astype(np.int64)
+        rid = (np.arange(k.size, dtype=np.int64) + first_row_id).astype(np.uint32)
+        return (torch.from_numpy(k[order].view(np.int32).copy()), torch.from_numpy(rid[order].view(np.int32).copy()),
+                torch.from_numpy(counts))
+
+    def local_join(self, build_keys, probe_keys):
+        b = build_keys.numpy().view(np.uint32)
+        p = probe_keys.numpy().view(np.uint32)
+        pos, cnt, ids = po.join_omnisci(b, p)
+        t = lambda a: torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
+        return t(pos), t(cnt), t(ids)
+
+    def gather(self, table, idx):
+        return table[idx.to(torch.int64)]
+
+
+def check_global(results, build_all: np.ndarray, probe_all: np.ndarray):
+    """results: list over ranks of (probe_row_ids, pos, cnt, build_row_ids) numpy uint32 arrays.
+    Canonical form: per global probe row the count, and the sorted list of global build row ids."""
+    bc, off, bids = po.join_bruteforce(build_all, probe_all)
+    seen = np.zeros(probe_all.size, dtype=bool)
+    for rid, pos, cnt, ids in results:
+        assert not seen[rid].any(), "a probe row was delivered to two ranks"
+        seen[rid] = True
+        assert np.array_equal(cnt.astype(np.uint64), bc[rid])
+        for i in range(rid.size):
+            got = np.sort(ids[pos[i]: pos[i] + cnt[i]]).astype(np.uint64)
+            assert np.array_equal(got, bids[int(off[rid[i]]): int(off[rid[i] + 1])]), (int(rid[i]),)
+    assert seen.all(), "some probe rows were lost in the exchange"

@@ -1,0 +1,106 @@
+"""Device pieces of the partitioned join through the C ABI, and the whole path with 2 ranks sharing the one GPU
+of the test box (gloo moves the buckets through the host there; on a multi-GPU node the same code runs over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 8, 256])
+@pytest.mark.parametrize("n", [0, 1, 5, 4095, 4096, 4097, 100003, 1 << 20])
+def test_partition_matches_hash_restatement(n, parts):
+    from dwarf_bench_amd import ops
+    from tests.pjoin_testlib import dest_of
+    keys = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    first = 1000003
+    ok, orid, cnt = ops.partition_by_hash(keys, first, parts)
+    h = keys.cpu().numpy().view(np.uint32)
+    d = dest_of(h, parts)
+    counts = cnt.cpu().numpy()
+    assert np.array_equal(counts, np.bincount(d, minlength=parts))
+    k2 = ok.cpu().numpy().view(np.uint32)
+    r2 = orid.cpu().numpy().view(np.uint32)
+    # every pair is (key, global row id of that key), buckets are contiguous and hold exactly their rows
+    assert np.array_equal(h[r2.astype(np.int64) - first], k2)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    for b in range(parts):
+        seg = r2[bounds[b]: bounds[b + 1]].astype(np.int64) - first
+        assert np.all(d[seg] == b)
+    assert np.array_equal(np.sort(r2), np.arange(first, first + n, dtype=np.uint32))
+
+
+def test_gather():
+    from dwarf_bench_amd import ops
+    table = ops.gen_uniform_u32(100000, 1, 0, 2**32 - 1)
+    idx = ops.gen_uniform_u32(333333, 2, 0, 99999)
+    got = ops.gather_u32(table, idx).cpu().numpy()
+    assert np.array_equal(got, table.cpu().numpy()[idx.cpu().numpy()])
+
+
+def test_bucket_balance_on_uniform_keys():
+    from dwarf_bench_amd import ops
+    n = 1 << 24
+    keys = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    _, _, cnt = ops.partition_by_hash(keys, 0, 8)
+    c = cnt.cpu().numpy()
+    assert c.sum() == n and c.max() / c.mean() < 1.01
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, key_hi, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dwarf_bench_amd import ops, pjoin
+        per = n // world
+        lo, hi = rank * per, (n if rank == world - 1 else (rank + 1) * per)
+        build = ops.gen_uniform_u32(hi - lo, 42, 1, key_hi, first_index=lo)
+        probe = ops.gen_uniform_u32(hi - lo, 43, 1, key_hi, first_index=lo)
+        res = pjoin.partitioned_join(build, probe, lo, lo)  # HipBackend
+        u = lambda t: t.cpu().numpy().view(np.uint32).copy()
+        q.put((rank, u(res.probe_row_ids), u(res.pos), u(res.cnt), u(res.build_row_ids)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,key_hi", [(3000, 2000), (50001, 10000)])
+def test_two_ranks_on_one_gpu(n, key_hi):
+    import torch.multiprocessing as mp
+    from tests.pjoin_testlib import check_global
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, key_hi, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    build_all = po.gen_uniform_u32(n, 42, 1, key_hi)
+    probe_all = po.gen_uniform_u32(n, 43, 1, key_hi)
+    if n <= 5000:
+        check_global([(o[1], o[2], o[3], o[4]) for o in outs], build_all, probe_all)
+    else:  # counts by global row id + total
+        want = po.join_counts_fast(build_all, probe_all)
+        got = np.zeros(n, dtype=np.uint64)
+        for _, rid, pos, cnt, ids in outs:
+            got[rid] = cnt
+            hit = cnt > 0
+            assert np.all(build_all[ids[pos[hit]]] == probe_all[rid[hit]])
+        assert np.array_equal(got, want)
