@@ -142,13 +142,28 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
 __global__ __launch_bounds__(256) void gb_reduce_kernel(const unsigned *__restrict__ partials,
                                                         GbGeometry geo, unsigned groups,
                                                         unsigned *__restrict__ out) {
-  const unsigned g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= groups) return;
-  const unsigned range = g / geo.range_groups, rel = g % geo.range_groups;
-  const unsigned *p = partials + static_cast<size_t>(range) * geo.chunk_slots * geo.range_groups + rel;
+  // 64 consecutive groups per workgroup (one 256-B line per partial table), the four waves split the
+  // partial tables between them; 8 independent loads in flight per lane
+  __shared__ unsigned s_sum[4][kWave];
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const unsigned g = blockIdx.x * kWave + lane;
   unsigned sum = 0;
-  for (unsigned s = 0; s < geo.chunk_slots; ++s) sum += p[static_cast<size_t>(s) * geo.range_groups];
-  out[g] = sum;
+  if (g < groups) {
+    const unsigned range = g / geo.range_groups, rel = g % geo.range_groups;
+    const unsigned *p = partials + static_cast<size_t>(range) * geo.chunk_slots * geo.range_groups + rel;
+    unsigned s = wave;
+    for (; s + 28 < geo.chunk_slots; s += 32) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(s + 4 * u) * geo.range_groups];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; s < geo.chunk_slots; s += 4) sum += p[static_cast<size_t>(s) * geo.range_groups];
+  }
+  s_sum[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && g < groups) out[g] = s_sum[0][lane] + s_sum[1][lane] + s_sum[2][lane] + s_sum[3][lane];
 }
 
 }  // namespace
@@ -196,7 +211,7 @@ extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals,
     hipLaunchKernelGGL((gb_aggregate_kernel<kGbSmallThreads>), dim3(grid), dim3(kGbSmallThreads), lds, s,
                        k4, v4, keys, vals, n, groups, geo, partials, hdr);
   }
-  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, partials, geo, groups,
+  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, s, partials, geo, groups,
                      out);
   return launch_status();
 }

@@ -13,6 +13,7 @@
 //     payload stored next to them, probe writes (key, build_val, probe_val) at the probe row or the
 //     0xFFFFFFFF sentinel.
 #include "dbhip_common.hpp"
+#include "join_common.hpp"
 #include "lookback.hpp"
 
 namespace dbhip {
@@ -245,17 +246,21 @@ __global__ __launch_bounds__(kJoinThreads) void ujoin_probe_kernel(
 
 using namespace dbhip;
 
-extern "C" size_t dbhip_join_workspace_bytes(size_t n_build) { return join_layout(n_build).total; }
+extern "C" size_t dbhip_join_workspace_bytes(size_t n_build) {
+  return jl_use(n_build) ? jl_layout(n_build).total : join_layout(n_build).total;
+}
 
 extern "C" int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids,
                                     void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (n_build && (!build_keys || !ids)) return DBHIP_EINVAL;
   if (n_build >= 0x7FFFFFFFull) return DBHIP_EINVAL;  // 32-bit ids / positions
-  const JoinLayout L = join_layout(n_build);
-  if (!ws_ok(workspace, workspace_bytes, L.total)) return DBHIP_EWORKSPACE;
+  if (!ws_ok(workspace, workspace_bytes, dbhip_join_workspace_bytes(n_build))) return DBHIP_EWORKSPACE;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
+  if (jl_use(n_build))  // large build sides: radix-partitioned, LDS-resident sub-tables (join_lds.hip)
+    return join_lds_build(build_keys, nullptr, n_build, ids, workspace, s, dev);
+  const JoinLayout L = join_layout(n_build);
   char *base = static_cast<char *>(workspace);
   JoinHeader *hdr = reinterpret_cast<JoinHeader *>(base);
   unsigned *keys = reinterpret_cast<unsigned *>(base + L.keys_off);
@@ -295,6 +300,8 @@ extern "C" int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, 
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   // the table geometry is a pure function of the build size: no read-back, no synchronisation
+  if (jl_use(n_build))
+    return join_lds_probe(probe_keys, n_probe, workspace, n_build, out_pos, out_count, as_stream(stream), dev);
   const JoinLayout L = join_layout(n_build);
   const char *base = static_cast<const char *>(workspace);
   const unsigned *keys = reinterpret_cast<const unsigned *>(base + L.keys_off);

@@ -1,0 +1,392 @@
+// join_lds.hip — dwarf 4a for large build sides: radix-partitioned build with LDS-resident sub-tables,
+// single-gather probe.  Same OmniSci semantics and outputs as join.hip (which stays the path for small
+// inputs): distinct-key table, per-key count, exclusive scan -> position, ids grouped by key, probe ->
+// {offset, count} (common/dpcpp/omnisci_hashtable.hpp:58-261).
+//
+// Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
+// — three per build row — and three 4-byte gathers per probe row (53 G/s).  LDS atomics run at
+// > 800 G/s.  So:
+//   build  1. partition the build column into K = n/4096 partitions by the HIGH bits of the mixed hash,
+//             in one or two levels of <= 512-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
+//             one global reservation per bucket per 4096-key tile, runs written contiguously);
+//          2. one workgroup per partition (jl_build): 8192-slot sub-table in LDS — ds_cmpst claim of
+//             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
+//             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
+//             as 16-byte slots {key, count, first id position, -} — the global table is the
+//             concatenation of the sub-tables;
+//   probe  one 16-byte gather per probe row (partition from the high hash bits, slot from the low
+//          bits, linear probing inside the 8192-slot sub-table), outputs written coalesced in row order.
+// A partition may hold any number of rows (duplicates do not matter); it may hold at most 8192
+// DISTINCT keys — with 4096 rows expected per partition and a mixing hash that is out of reach for
+// real data; if it happens the build sets DBHIP_DEV_TABLE_FULL.
+#include "dbhip_common.hpp"
+#include "join_common.hpp"
+
+namespace dbhip {
+namespace {
+
+constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
+constexpr int kJlThreads = 256;
+constexpr int kJlKpt = 16;
+constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile
+constexpr int kJlBuildThreads = 1024;
+
+__device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key)) * parts) >> 32);
+}
+
+// ---- level histograms ---------------------------------------------------------------------------
+// level 0: whole column -> K1 buckets (bucket = pid / K2).  level 1: per level-0 bucket -> K2 sub-buckets.
+__global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__restrict__ keys, size_t n,
+                                                              unsigned parts, unsigned k2_shift,
+                                                              unsigned k1, unsigned long long *counts) {
+  extern __shared__ unsigned s_hist[];
+  for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_hist[i] = 0;
+  __syncthreads();
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
+    atomicAdd(&s_hist[jl_pid(keys[i], parts) >> k2_shift], 1u);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
+    if (s_hist[i]) atomicAdd(&counts[i], static_cast<unsigned long long>(s_hist[i]));
+}
+
+// starts[b] = exclusive scan of counts; cursors = starts; tile_starts[b] = exclusive scan of the number
+// of 4096-row tiles of every bucket (so a 1-D grid can find its (bucket, tile) by binary search).
+// One workgroup of 1024 threads; `count` <= 2^18 entries.
+__global__ __launch_bounds__(1024) void jl_offsets_kernel(const unsigned long long *__restrict__ counts,
+                                                          unsigned count, unsigned long long *starts,
+                                                          unsigned long long *cursors,
+                                                          unsigned long long *tile_starts) {
+  __shared__ unsigned long long s_sum[1024], s_tiles[1024];
+  const unsigned tid = threadIdx.x;
+  const unsigned per = (count + 1023) / 1024;
+  const unsigned lo = tid * per, hi = lo + per < count ? lo + per : count;
+  unsigned long long sum = 0, tiles = 0;
+  for (unsigned i = lo; i < hi; ++i) {
+    sum += counts[i];
+    tiles += (counts[i] + kJlTile - 1) / kJlTile;
+  }
+  s_sum[tid] = sum;
+  s_tiles[tid] = tiles;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long a = 0, b = 0;
+    for (unsigned i = 0; i < 1024; ++i) {
+      const unsigned long long x = s_sum[i], y = s_tiles[i];
+      s_sum[i] = a;
+      s_tiles[i] = b;
+      a += x;
+      b += y;
+    }
+  }
+  __syncthreads();
+  unsigned long long run = s_sum[tid], trun = s_tiles[tid];
+  for (unsigned i = lo; i < hi; ++i) {
+    starts[i] = run;
+    cursors[i] = run;
+    if (tile_starts) tile_starts[i] = trun;
+    run += counts[i];
+    trun += (counts[i] + kJlTile - 1) / kJlTile;
+  }
+  if ((lo < count && hi == count) || (count == 0 && tid == 0)) {  // owner of the last entry: terminator
+    starts[count] = run;
+    if (tile_starts) tile_starts[count] = trun;
+  }
+}
+
+// level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
+__global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
+                                                                 const unsigned *__restrict__ row_ids, size_t n,
+                                                                 unsigned parts, unsigned k2_shift, unsigned k1,
+                                                                 unsigned long long *cursors,
+                                                                 unsigned *__restrict__ out_keys,
+                                                                 unsigned *__restrict__ out_rids) {
+  extern __shared__ unsigned s_mem[];
+  unsigned *s_cnt = s_mem;
+  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem + ((k1 + 1) & ~1u));
+  const size_t tiles = (n + kJlTile - 1) / kJlTile;
+  for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const size_t base = tile * kJlTile;
+    for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_cnt[i] = 0;
+    __syncthreads();
+    unsigned key[kJlKpt], rank[kJlKpt], dest[kJlKpt];
+#pragma unroll
+    for (int j = 0; j < kJlKpt; ++j) {
+      const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+      const bool valid = idx < n;
+      key[j] = valid ? keys[idx] : 0u;
+      dest[j] = valid ? jl_pid(key[j], parts) >> k2_shift : k1;
+      rank[j] = valid ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
+      s_base[i] = s_cnt[i] ? atomicAdd(&cursors[i], static_cast<unsigned long long>(s_cnt[i])) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kJlKpt; ++j) {
+      if (dest[j] < k1) {
+        const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+        const size_t slot = s_base[dest[j]] + rank[j];
+        out_keys[slot] = key[j];
+        out_rids[slot] = row_ids ? row_ids[idx] : static_cast<unsigned>(idx);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// (bucket, tile-in-bucket) of virtual tile `vt` by binary search over tile_starts[0..k1]
+__device__ __forceinline__ bool jl_locate(const unsigned long long *__restrict__ tile_starts, unsigned k1,
+                                          unsigned long long vt, unsigned *bucket, unsigned long long *tile) {
+  if (vt >= tile_starts[k1]) return false;
+  unsigned lo = 0, hi = k1;  // find largest b with tile_starts[b] <= vt
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) / 2;
+    if (tile_starts[mid] <= vt) lo = mid; else hi = mid;
+  }
+  *bucket = lo;
+  *tile = vt - tile_starts[lo];
+  return true;
+}
+
+__global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__restrict__ keys,
+                                                              const unsigned long long *__restrict__ starts0,
+                                                              const unsigned long long *__restrict__ tile_starts,
+                                                              unsigned parts, unsigned k1, unsigned k2,
+                                                              unsigned long long *counts1) {
+  extern __shared__ unsigned s_hist[];
+  unsigned bucket;
+  unsigned long long tile;
+  if (!jl_locate(tile_starts, k1, blockIdx.x, &bucket, &tile)) return;
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads) s_hist[i] = 0;
+  __syncthreads();
+  const size_t lo = starts0[bucket] + tile * kJlTile;
+  const size_t hi = lo + kJlTile < starts0[bucket + 1] ? lo + kJlTile : starts0[bucket + 1];
+  for (size_t i = lo + threadIdx.x; i < hi; i += kJlThreads) atomicAdd(&s_hist[jl_pid(keys[i], parts) & (k2 - 1)], 1u);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
+    if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
+}
+
+__global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned *__restrict__ keys,
+                                                                 const unsigned *__restrict__ rids,
+                                                                 const unsigned long long *__restrict__ starts0,
+                                                                 const unsigned long long *__restrict__ tile_starts,
+                                                                 unsigned parts, unsigned k1, unsigned k2,
+                                                                 unsigned long long *cursors1,
+                                                                 unsigned *__restrict__ out_keys,
+                                                                 unsigned *__restrict__ out_rids) {
+  extern __shared__ unsigned s_mem[];
+  unsigned *s_cnt = s_mem;
+  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem + ((k2 + 1) & ~1u));
+  unsigned bucket;
+  unsigned long long tile;
+  if (!jl_locate(tile_starts, k1, blockIdx.x, &bucket, &tile)) return;
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads) s_cnt[i] = 0;
+  __syncthreads();
+  const size_t lo = starts0[bucket] + tile * kJlTile;
+  const size_t hi = starts0[bucket + 1];
+  unsigned key[kJlKpt], rid[kJlKpt], rank[kJlKpt], dest[kJlKpt];
+#pragma unroll
+  for (int j = 0; j < kJlKpt; ++j) {
+    const size_t idx = lo + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+    const bool valid = idx < hi && idx < lo + kJlTile;
+    key[j] = valid ? keys[idx] : 0u;
+    rid[j] = valid ? rids[idx] : 0u;
+    dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
+    rank[j] = valid ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
+    s_base[i] = s_cnt[i] ? atomicAdd(&cursors1[static_cast<size_t>(bucket) * k2 + i],
+                                     static_cast<unsigned long long>(s_cnt[i]))
+                         : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kJlKpt; ++j) {
+    if (dest[j] < k2) {
+      const size_t slot = s_base[dest[j]] + rank[j];
+      out_keys[slot] = key[j];
+      out_rids[slot] = rid[j];
+    }
+  }
+}
+
+// ---- per-partition build in LDS --------------------------------------------------------------------
+__global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
+                                                                   const unsigned *__restrict__ prids,
+                                                                   const unsigned long long *__restrict__ starts,
+                                                                   u32x4 *__restrict__ table,
+                                                                   unsigned *__restrict__ ids, unsigned *status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
+  unsigned *lk = s_lds;                  // keys
+  unsigned *lc = s_lds + kJlSubSlots;    // counts
+  unsigned *lp = s_lds + 2 * kJlSubSlots;  // positions (start, then bumped to end by the fill)
+  __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const size_t part = blockIdx.x;
+  const size_t lo = starts[part], hi = starts[part + 1];
+
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
+    lk[i] = kEmptyKey;
+    lc[i] = 0;
+  }
+  __syncthreads();
+  // 1. claim the key's slot (ds_cmpst) and count the row (ds_add)
+  for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
+    const unsigned key = pkeys[i];
+    unsigned s = fmix32(key) & kJlSubMask;
+    unsigned tries = 0;
+    while (true) {
+      const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
+      if (old == kEmptyKey || old == key) {
+        atomicAdd(&lc[s], 1u);
+        break;
+      }
+      s = (s + 1) & kJlSubMask;
+      if (++tries > kJlSubMask) {
+        atomicOr(status, DBHIP_DEV_TABLE_FULL);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // 2. exclusive scan of the 8192 counts -> first id position of every slot (8 slots per thread)
+  constexpr unsigned kPer = kJlSubSlots / kJlBuildThreads;
+  unsigned c[kPer], mine = 0;
+#pragma unroll
+  for (unsigned j = 0; j < kPer; ++j) {
+    c[j] = lc[tid * kPer + j];
+    mine += c[j];
+  }
+  const unsigned incl = wave_inclusive_scan(mine);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned run = static_cast<unsigned>(lo) + incl - mine;
+  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+  for (unsigned j = 0; j < kPer; ++j) {
+    lp[tid * kPer + j] = run;
+    run += c[j];
+  }
+  __syncthreads();
+  // 3. fill: ids[pos[slot]++] = row id (the partition's rows are still in L2)
+  for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
+    const unsigned key = pkeys[i];
+    unsigned s = fmix32(key) & kJlSubMask;
+    for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
+    if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = prids[i];
+  }
+  __syncthreads();
+  // 4. publish the sub-table: {key, count, first position, 0}
+  u32x4 *dst = table + part * kJlSubSlots;
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
+    const unsigned cnt = lc[i];
+    dst[i] = u32x4{lk[i], cnt, lp[i] - cnt, 0u};
+  }
+}
+
+__global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
+                                                              const u32x4 *__restrict__ table, unsigned parts,
+                                                              unsigned *__restrict__ out_pos,
+                                                              unsigned *__restrict__ out_cnt) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned key = probe[i];
+    const unsigned h = fmix32(key);
+    const u32x4 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+    unsigned s = h & kJlSubMask, pos = 0, cnt = 0;
+    for (unsigned tries = 0; tries <= kJlSubMask; ++tries) {
+      const u32x4 e = sub[s];
+      if (e.x == key) {
+        cnt = e.y;
+        pos = e.z;
+        break;
+      }
+      if (e.x == kEmptyKey) break;
+      s = (s + 1) & kJlSubMask;
+    }
+    out_pos[i] = pos;
+    out_cnt[i] = cnt;
+  }
+}
+
+inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
+  const size_t want = (items + kJlThreads - 1) / kJlThreads;
+  const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
+  return static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace
+
+// ---- host side (called from join.hip's entry points) ---------------------------------------------------
+int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n, unsigned *ids, void *workspace,
+                   hipStream_t s, const DeviceInfo &dev) {
+  const JlLayout L = jl_layout(n);
+  char *base = static_cast<char *>(workspace);
+  unsigned *status = reinterpret_cast<unsigned *>(base);
+  u32x4 *table = reinterpret_cast<u32x4 *>(base + L.table_off);
+  unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);
+  unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);
+  unsigned *k_b = reinterpret_cast<unsigned *>(base + L.keys_b_off);
+  unsigned *r_b = reinterpret_cast<unsigned *>(base + L.rids_b_off);
+  unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + L.meta_off);
+  // meta: counts0[k1] | starts0[k1+1] | cursors0[k1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
+  unsigned long long *counts0 = meta;
+  unsigned long long *starts0 = counts0 + L.k1;
+  unsigned long long *cursors0 = starts0 + L.k1 + 1;
+  unsigned long long *tstarts0 = cursors0 + L.k1;
+  unsigned long long *counts1 = tstarts0 + L.k1 + 1;
+  unsigned long long *starts1 = counts1 + L.parts;
+  unsigned long long *cursors1 = starts1 + L.parts + 1;
+
+  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = hipMemsetAsync(meta, 0, L.meta_bytes, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+
+  const unsigned k2_shift = L.log2_k2;
+  const size_t lds0 = ((L.k1 + 1) & ~1u) * sizeof(unsigned) + L.k1 * sizeof(unsigned long long);
+  hipLaunchKernelGGL(jl_hist0_kernel, dim3(jl_grid(n, dev, 8)), dim3(kJlThreads), L.k1 * sizeof(unsigned), s,
+                     build_keys, n, L.parts, k2_shift, L.k1, counts0);
+  hipLaunchKernelGGL(jl_offsets_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, starts0, cursors0, tstarts0);
+  {
+    const size_t tiles = (n + kJlTile - 1) / kJlTile;
+    const size_t cap = static_cast<size_t>(dev.cus) * 8;
+    hipLaunchKernelGGL(jl_scatter0_kernel, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
+                       lds0, s, build_keys, row_ids, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
+  }
+  const unsigned *pk = k_a, *pr = r_a;
+  const unsigned long long *pstarts = starts0;
+  if (L.k2 > 1) {
+    const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
+    const size_t lds1 = ((L.k2 + 1) & ~1u) * sizeof(unsigned) + L.k2 * sizeof(unsigned long long);
+    hipLaunchKernelGGL(jl_hist1_kernel, dim3(vtiles), dim3(kJlThreads), L.k2 * sizeof(unsigned), s, k_a, starts0,
+                       tstarts0, L.parts, L.k1, L.k2, counts1);
+    hipLaunchKernelGGL(jl_offsets_kernel, dim3(1), dim3(1024), 0, s, counts1, L.parts, starts1, cursors1,
+                       static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
+                       L.parts, L.k1, L.k2, cursors1, k_b, r_b);
+    pk = k_b;
+    pr = r_b;
+    pstarts = starts1;
+  }
+  const size_t build_lds = 3 * kJlSubSlots * sizeof(unsigned);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, pk, pr, pstarts, table, ids,
+                     status);
+  return launch_status();
+}
+
+int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *workspace, size_t n_build,
+                   unsigned *out_pos, unsigned *out_cnt, hipStream_t s, const DeviceInfo &dev) {
+  const JlLayout L = jl_layout(n_build);
+  const u32x4 *table = reinterpret_cast<const u32x4 *>(static_cast<const char *>(workspace) + L.table_off);
+  hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
+                     table, L.parts, out_pos, out_cnt);
+  return launch_status();
+}
+
+}  // namespace dbhip
