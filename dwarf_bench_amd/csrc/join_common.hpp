@@ -6,11 +6,11 @@
 
 namespace dbhip {
 
-constexpr unsigned kJlSubSlots = 8192;  // slots of one LDS sub-table (96 KiB of LDS with counts/positions)
+constexpr unsigned kJlSubSlots = 4096;  // slots of one LDS sub-table (48 KiB of LDS with counts/positions)
 constexpr unsigned kJlSubMask = kJlSubSlots - 1;
-constexpr unsigned kJlRowsPerPart = 4096;           // expected rows per partition (load factor <= 0.5)
+constexpr unsigned kJlRowsPerPart = 2048;           // expected rows per partition (load factor <= 0.5)
 constexpr size_t kJlMinRows = static_cast<size_t>(1) << 16;  // below: the HBM-table path of join.hip
-constexpr size_t kJlMaxRows = static_cast<size_t>(1) << 30;  // above: 2^18 partitions would overfill
+constexpr size_t kJlMaxRows = static_cast<size_t>(1) << 31;  // above: 2^20 partitions would overfill
 
 inline bool jl_use(size_t n_build) {
   static const int force = [] {
@@ -30,9 +30,9 @@ struct JlLayout {
 inline JlLayout jl_layout(size_t n) {
   JlLayout L;
   unsigned lg = 0;
-  while ((static_cast<size_t>(kJlRowsPerPart) << lg) < n && lg < 18) ++lg;
+  while ((static_cast<size_t>(kJlRowsPerPart) << lg) < n && lg < 20) ++lg;
   L.parts = 1u << lg;
-  if (L.parts <= 512) {
+  if (L.parts <= 1024) {  // one scatter level handles up to 1024 buckets
     L.log2_k2 = 0;
   } else {
     L.log2_k2 = lg / 2;
@@ -46,7 +46,7 @@ inline JlLayout jl_layout(size_t n) {
   L.keys_b_off = L.rids_a_off + col;
   L.rids_b_off = L.keys_b_off + (L.k2 > 1 ? col : 0);
   L.meta_off = L.rids_b_off + (L.k2 > 1 ? col : 0);
-  L.meta_bytes = sizeof(unsigned long long) * (4 * static_cast<size_t>(L.k1) + 2 + 3 * static_cast<size_t>(L.parts) + 1);
+  L.meta_bytes = sizeof(unsigned long long) * ((2 * 64 + 2) * static_cast<size_t>(L.k1) + 2 + 3 * static_cast<size_t>(L.parts) + 1);  // 64 = kJlGroups
   L.total = align_up(L.meta_off + L.meta_bytes, kWsAlign);
   return L;
 }

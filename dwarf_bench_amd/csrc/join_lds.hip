@@ -6,18 +6,18 @@
 // Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
 // — three per build row — and three 4-byte gathers per probe row (53 G/s).  LDS atomics run at
 // > 800 G/s.  So:
-//   build  1. partition the build column into K = n/4096 partitions by the HIGH bits of the mixed hash,
-//             in one or two levels of <= 512-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
+//   build  1. partition the build column into K = n/2048 partitions by the HIGH bits of the mixed hash,
+//             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
 //             one global reservation per bucket per 4096-key tile, runs written contiguously);
-//          2. one workgroup per partition (jl_build): 8192-slot sub-table in LDS — ds_cmpst claim of
+//          2. one workgroup per partition (jl_build): 4096-slot sub-table in LDS — ds_cmpst claim of
 //             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
 //             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
 //             as 16-byte slots {key, count, first id position, -} — the global table is the
 //             concatenation of the sub-tables;
 //   probe  one 16-byte gather per probe row (partition from the high hash bits, slot from the low
-//          bits, linear probing inside the 8192-slot sub-table), outputs written coalesced in row order.
-// A partition may hold any number of rows (duplicates do not matter); it may hold at most 8192
-// DISTINCT keys — with 4096 rows expected per partition and a mixing hash that is out of reach for
+//          bits, linear probing inside the 4096-slot sub-table), outputs written coalesced in row order.
+// A partition may hold any number of rows (duplicates do not matter); it may hold at most 4096
+// DISTINCT keys — with 2048 rows expected per partition and a mixing hash that is out of reach for
 // real data; if it happens the build sets DBHIP_DEV_TABLE_FULL.
 #include "dbhip_common.hpp"
 #include "join_common.hpp"
@@ -29,70 +29,188 @@ constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
 constexpr int kJlThreads = 256;
 constexpr int kJlKpt = 16;
 constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile
-constexpr int kJlBuildThreads = 1024;
+constexpr int kJlBuildThreads = 512;
 
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
   return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key)) * parts) >> 32);
 }
 
-// ---- level histograms ---------------------------------------------------------------------------
-// level 0: whole column -> K1 buckets (bucket = pid / K2).  level 1: per level-0 bucket -> K2 sub-buckets.
+// ---- level 0: histogram per (tile group, bucket) --------------------------------------------------
+// The column's 4096-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
+// of every bucket (its rows' share), so the scatter's reservations on one cursor come from 1/64 of
+// the tiles: 16384 tiles bumping the SAME 128 cursors serialise on the memory-side atomic unit
+// (measured: 544 us for a 768 MiB scatter).
+constexpr unsigned kJlGroups = 64;
+constexpr unsigned kJlHistWgPerGroup = 32;
+
+__device__ __forceinline__ size_t jl_tiles_per_group(size_t n) {
+  const size_t tiles = (n + kJlTile - 1) / kJlTile;
+  return (tiles + kJlGroups - 1) / kJlGroups;
+}
+
 __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__restrict__ keys, size_t n,
                                                               unsigned parts, unsigned k2_shift,
-                                                              unsigned k1, unsigned long long *counts) {
+                                                              unsigned k1, unsigned long long *counts_g) {
   extern __shared__ unsigned s_hist[];
+  const unsigned group = blockIdx.x / kJlHistWgPerGroup, w = blockIdx.x % kJlHistWgPerGroup;
+  const size_t tpg = jl_tiles_per_group(n);
+  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
+  size_t hi = lo + tpg * kJlTile;
+  hi = hi < n ? hi : n;
+  if (lo >= hi) return;
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_hist[i] = 0;
   __syncthreads();
-  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
+  for (size_t i = lo + static_cast<size_t>(w) * kJlThreads + threadIdx.x; i < hi;
+       i += static_cast<size_t>(kJlHistWgPerGroup) * kJlThreads)
     atomicAdd(&s_hist[jl_pid(keys[i], parts) >> k2_shift], 1u);
   __syncthreads();
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
-    if (s_hist[i]) atomicAdd(&counts[i], static_cast<unsigned long long>(s_hist[i]));
+    if (s_hist[i]) atomicAdd(&counts_g[static_cast<size_t>(group) * k1 + i], static_cast<unsigned long long>(s_hist[i]));
 }
 
-// starts[b] = exclusive scan of counts; cursors = starts; tile_starts[b] = exclusive scan of the number
-// of 4096-row tiles of every bucket (so a 1-D grid can find its (bucket, tile) by binary search).
-// One workgroup of 1024 threads; `count` <= 2^18 entries.
-__global__ __launch_bounds__(1024) void jl_offsets_kernel(const unsigned long long *__restrict__ counts,
-                                                          unsigned count, unsigned long long *starts,
-                                                          unsigned long long *cursors,
-                                                          unsigned long long *tile_starts) {
-  __shared__ unsigned long long s_sum[1024], s_tiles[1024];
-  const unsigned tid = threadIdx.x;
-  const unsigned per = (count + 1023) / 1024;
-  const unsigned lo = tid * per, hi = lo + per < count ? lo + per : count;
-  unsigned long long sum = 0, tiles = 0;
-  for (unsigned i = lo; i < hi; ++i) {
-    sum += counts[i];
-    tiles += (counts[i] + kJlTile - 1) / kJlTile;
-  }
-  s_sum[tid] = sum;
-  s_tiles[tid] = tiles;
+// bucket starts, per-group cursors and the tile index of every bucket (for the 1-D grid of level 1).
+// One workgroup, thread b owns bucket b (k1 <= 1024).
+__global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long long *__restrict__ counts_g,
+                                                           unsigned k1, unsigned long long *cursors_g,
+                                                           unsigned long long *starts, unsigned long long *tile_starts) {
+  __shared__ unsigned long long s_tot[1024], s_start[1025], s_tstart[1025];
+  const unsigned b = threadIdx.x;
+  unsigned long long tot = 0;
+  if (b < k1)
+    for (unsigned g = 0; g < kJlGroups; ++g) tot += counts_g[static_cast<size_t>(g) * k1 + b];
+  s_tot[b] = tot;
   __syncthreads();
-  if (tid == 0) {
-    unsigned long long a = 0, b = 0;
-    for (unsigned i = 0; i < 1024; ++i) {
-      const unsigned long long x = s_sum[i], y = s_tiles[i];
-      s_sum[i] = a;
-      s_tiles[i] = b;
-      a += x;
-      b += y;
+  if (b == 0) {
+    unsigned long long run = 0, trun = 0;
+    for (unsigned i = 0; i < k1; ++i) {
+      s_start[i] = run;
+      s_tstart[i] = trun;
+      run += s_tot[i];
+      trun += (s_tot[i] + kJlTile - 1) / kJlTile;
+    }
+    s_start[k1] = run;
+    s_tstart[k1] = trun;
+  }
+  __syncthreads();
+  if (b < k1) {
+    starts[b] = s_start[b];
+    tile_starts[b] = s_tstart[b];
+    unsigned long long run = s_start[b];
+    for (unsigned g = 0; g < kJlGroups; ++g) {
+      cursors_g[static_cast<size_t>(g) * k1 + b] = run;
+      run += counts_g[static_cast<size_t>(g) * k1 + b];
+    }
+  }
+  if (b == 0) {
+    starts[k1] = s_start[k1];
+    tile_starts[k1] = s_tstart[k1];
+  }
+}
+
+// level 1: bucket b's k2 sub-buckets live inside [starts0[b], starts0[b+1]).  One workgroup per bucket.
+__global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned long long *__restrict__ counts1,
+                                                                 const unsigned long long *__restrict__ starts0,
+                                                                 unsigned k1, unsigned k2, unsigned long long *starts1,
+                                                                 unsigned long long *cursors1) {
+  __shared__ unsigned s_wsum[kJlThreads / kWave];
+  const unsigned b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned per = (k2 + kJlThreads - 1) / kJlThreads;  // <= 4
+  unsigned c[4] = {0, 0, 0, 0}, mine = 0;
+#pragma unroll
+  for (unsigned u = 0; u < 4; ++u) {
+    const unsigned sidx = tid * per + u;
+    if (u < per && sidx < k2) c[u] = static_cast<unsigned>(counts1[static_cast<size_t>(b) * k2 + sidx]);
+    mine += c[u];
+  }
+  const unsigned incl = wave_inclusive_scan(mine);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long run = starts0[b] + incl - mine;
+  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+  for (unsigned u = 0; u < 4; ++u) {
+    const unsigned sidx = tid * per + u;
+    if (u < per && sidx < k2) {
+      starts1[static_cast<size_t>(b) * k2 + sidx] = run;
+      cursors1[static_cast<size_t>(b) * k2 + sidx] = run;
+      run += c[u];
+    }
+  }
+  if (b == k1 - 1 && tid == 0) starts1[static_cast<size_t>(k1) * k2] = starts0[k1];
+}
+
+// Scatter of one 4096-row tile into `nb` (<= 1024) buckets, staged through LDS so that the global
+// writes are runs: rows are ranked inside their bucket with LDS atomics, the tile is re-ordered by
+// bucket in LDS, every bucket's run gets ONE global reservation, and consecutive lanes then write
+// consecutive addresses of a run.  LEVEL selects how the bucket is recomputed from the key on the way
+// out (0: pid >> arg, 1: pid & arg).  dest[j] == nb marks an invalid (out-of-range) row.
+// LDS: cnt[nb] | excl[nb] | base[nb] (u64) | keys[4096] | rids[4096] | 4 wave sums.
+constexpr size_t jl_scatter_lds_bytes(unsigned nb) {
+  return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + 16;
+}
+template <int LEVEL>
+__device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], const unsigned (&rid)[kJlKpt],
+                                                const unsigned (&dest)[kJlKpt], unsigned nb, unsigned parts,
+                                                unsigned arg, unsigned long long *cursors,
+                                                unsigned *__restrict__ out_keys, unsigned *__restrict__ out_rids,
+                                                unsigned *s_mem) {
+  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem);  // 8-byte aligned first
+  unsigned *s_cnt = s_mem + 2 * nb;
+  unsigned *s_excl = s_cnt + nb;
+  unsigned *s_keys = s_excl + nb;
+  unsigned *s_rids = s_keys + kJlTile;
+  unsigned *s_wsum = s_rids + kJlTile;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+
+  for (unsigned i = tid; i < nb; i += kJlThreads) s_cnt[i] = 0;
+  __syncthreads();
+  unsigned rank[kJlKpt];
+#pragma unroll
+  for (int j = 0; j < kJlKpt; ++j) rank[j] = dest[j] < nb ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
+  __syncthreads();
+  // exclusive scan of the bucket counts (nb <= 1024: up to 4 consecutive buckets per thread)
+  const unsigned per = (nb + kJlThreads - 1) / kJlThreads;
+  unsigned c[4] = {0, 0, 0, 0}, mine = 0;
+#pragma unroll
+  for (unsigned u = 0; u < 4; ++u) {
+    const unsigned b = tid * per + u;
+    if (u < per && b < nb) c[u] = s_cnt[b];
+    mine += c[u];
+  }
+  const unsigned incl = wave_inclusive_scan(mine);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned run = incl - mine;
+  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+  const unsigned total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+  for (unsigned u = 0; u < 4; ++u) {
+    const unsigned b = tid * per + u;
+    if (u < per && b < nb) {
+      s_excl[b] = run;
+      s_base[b] = c[u] ? atomicAdd(&cursors[b], static_cast<unsigned long long>(c[u])) : 0ull;
+      run += c[u];
     }
   }
   __syncthreads();
-  unsigned long long run = s_sum[tid], trun = s_tiles[tid];
-  for (unsigned i = lo; i < hi; ++i) {
-    starts[i] = run;
-    cursors[i] = run;
-    if (tile_starts) tile_starts[i] = trun;
-    run += counts[i];
-    trun += (counts[i] + kJlTile - 1) / kJlTile;
+#pragma unroll
+  for (int j = 0; j < kJlKpt; ++j) {
+    if (dest[j] < nb) {
+      const unsigned p = s_excl[dest[j]] + rank[j];
+      s_keys[p] = key[j];
+      s_rids[p] = rid[j];
+    }
   }
-  if ((lo < count && hi == count) || (count == 0 && tid == 0)) {  // owner of the last entry: terminator
-    starts[count] = run;
-    if (tile_starts) tile_starts[count] = trun;
+  __syncthreads();
+  for (unsigned p = tid; p < total; p += kJlThreads) {
+    const unsigned k = s_keys[p];
+    const unsigned pid = jl_pid(k, parts);
+    const unsigned d = LEVEL == 0 ? pid >> arg : pid & arg;
+    const size_t slot = s_base[d] + (p - s_excl[d]);
+    out_keys[slot] = k;
+    out_rids[slot] = s_rids[p];
   }
+  __syncthreads();  // LDS is reused by the next tile
 }
 
 // level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
@@ -102,37 +220,21 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
                                                                  unsigned long long *cursors,
                                                                  unsigned *__restrict__ out_keys,
                                                                  unsigned *__restrict__ out_rids) {
-  extern __shared__ unsigned s_mem[];
-  unsigned *s_cnt = s_mem;
-  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem + ((k1 + 1) & ~1u));
+  extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
   const size_t tiles = (n + kJlTile - 1) / kJlTile;
   for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const size_t base = tile * kJlTile;
-    for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_cnt[i] = 0;
-    __syncthreads();
-    unsigned key[kJlKpt], rank[kJlKpt], dest[kJlKpt];
+    unsigned key[kJlKpt], rid[kJlKpt], dest[kJlKpt];
 #pragma unroll
     for (int j = 0; j < kJlKpt; ++j) {
       const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
       const bool valid = idx < n;
       key[j] = valid ? keys[idx] : 0u;
+      rid[j] = valid ? (row_ids ? row_ids[idx] : static_cast<unsigned>(idx)) : 0u;
       dest[j] = valid ? jl_pid(key[j], parts) >> k2_shift : k1;
-      rank[j] = valid ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
     }
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
-      s_base[i] = s_cnt[i] ? atomicAdd(&cursors[i], static_cast<unsigned long long>(s_cnt[i])) : 0ull;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kJlKpt; ++j) {
-      if (dest[j] < k1) {
-        const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
-        const size_t slot = s_base[dest[j]] + rank[j];
-        out_keys[slot] = key[j];
-        out_rids[slot] = row_ids ? row_ids[idx] : static_cast<unsigned>(idx);
-      }
-    }
-    __syncthreads();
+    const size_t group = tile / jl_tiles_per_group(n);  // this tile bumps only its group's cursors
+    jl_scatter_tile<0>(key, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem);
   }
 }
 
@@ -177,17 +279,13 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
                                                                  unsigned long long *cursors1,
                                                                  unsigned *__restrict__ out_keys,
                                                                  unsigned *__restrict__ out_rids) {
-  extern __shared__ unsigned s_mem[];
-  unsigned *s_cnt = s_mem;
-  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem + ((k2 + 1) & ~1u));
+  extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
   unsigned bucket;
   unsigned long long tile;
   if (!jl_locate(tile_starts, k1, blockIdx.x, &bucket, &tile)) return;
-  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads) s_cnt[i] = 0;
-  __syncthreads();
   const size_t lo = starts0[bucket] + tile * kJlTile;
   const size_t hi = starts0[bucket + 1];
-  unsigned key[kJlKpt], rid[kJlKpt], rank[kJlKpt], dest[kJlKpt];
+  unsigned key[kJlKpt], rid[kJlKpt], dest[kJlKpt];
 #pragma unroll
   for (int j = 0; j < kJlKpt; ++j) {
     const size_t idx = lo + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
@@ -195,22 +293,9 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
     key[j] = valid ? keys[idx] : 0u;
     rid[j] = valid ? rids[idx] : 0u;
     dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
-    rank[j] = valid ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
   }
-  __syncthreads();
-  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
-    s_base[i] = s_cnt[i] ? atomicAdd(&cursors1[static_cast<size_t>(bucket) * k2 + i],
-                                     static_cast<unsigned long long>(s_cnt[i]))
-                         : 0ull;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kJlKpt; ++j) {
-    if (dest[j] < k2) {
-      const size_t slot = s_base[dest[j]] + rank[j];
-      out_keys[slot] = key[j];
-      out_rids[slot] = rid[j];
-    }
-  }
+  jl_scatter_tile<1>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2, out_keys,
+                     out_rids, s_mem);
 }
 
 // ---- per-partition build in LDS --------------------------------------------------------------------
@@ -291,6 +376,8 @@ __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__
                                                               const u32x4 *__restrict__ table, unsigned parts,
                                                               unsigned *__restrict__ out_pos,
                                                               unsigned *__restrict__ out_cnt) {
+  // one row per lane per step at full occupancy (32 waves per CU): the probe is pure memory latency,
+  // one random 16-byte line per row; unrolling rows per lane measured slower (2.1 vs 1.7 ms at 2^26)
   const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
     const unsigned key = probe[i];
@@ -332,11 +419,11 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   unsigned *k_b = reinterpret_cast<unsigned *>(base + L.keys_b_off);
   unsigned *r_b = reinterpret_cast<unsigned *>(base + L.rids_b_off);
   unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + L.meta_off);
-  // meta: counts0[k1] | starts0[k1+1] | cursors0[k1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
+  // meta: counts0g[G*k1] | cursors0g[G*k1] | starts0[k1+1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
   unsigned long long *counts0 = meta;
-  unsigned long long *starts0 = counts0 + L.k1;
-  unsigned long long *cursors0 = starts0 + L.k1 + 1;
-  unsigned long long *tstarts0 = cursors0 + L.k1;
+  unsigned long long *cursors0 = counts0 + static_cast<size_t>(kJlGroups) * L.k1;
+  unsigned long long *starts0 = cursors0 + static_cast<size_t>(kJlGroups) * L.k1;
+  unsigned long long *tstarts0 = starts0 + L.k1 + 1;
   unsigned long long *counts1 = tstarts0 + L.k1 + 1;
   unsigned long long *starts1 = counts1 + L.parts;
   unsigned long long *cursors1 = starts1 + L.parts + 1;
@@ -346,10 +433,10 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   if (e != hipSuccess) return static_cast<int>(e);
 
   const unsigned k2_shift = L.log2_k2;
-  const size_t lds0 = ((L.k1 + 1) & ~1u) * sizeof(unsigned) + L.k1 * sizeof(unsigned long long);
-  hipLaunchKernelGGL(jl_hist0_kernel, dim3(jl_grid(n, dev, 8)), dim3(kJlThreads), L.k1 * sizeof(unsigned), s,
-                     build_keys, n, L.parts, k2_shift, L.k1, counts0);
-  hipLaunchKernelGGL(jl_offsets_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, starts0, cursors0, tstarts0);
+  const size_t lds0 = jl_scatter_lds_bytes(L.k1);
+  hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), L.k1 * sizeof(unsigned),
+                     s, build_keys, n, L.parts, k2_shift, L.k1, counts0);
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, cursors0, starts0, tstarts0);
   {
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
@@ -360,11 +447,11 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const unsigned long long *pstarts = starts0;
   if (L.k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
-    const size_t lds1 = ((L.k2 + 1) & ~1u) * sizeof(unsigned) + L.k2 * sizeof(unsigned long long);
+    const size_t lds1 = jl_scatter_lds_bytes(L.k2);
     hipLaunchKernelGGL(jl_hist1_kernel, dim3(vtiles), dim3(kJlThreads), L.k2 * sizeof(unsigned), s, k_a, starts0,
                        tstarts0, L.parts, L.k1, L.k2, counts1);
-    hipLaunchKernelGGL(jl_offsets_kernel, dim3(1), dim3(1024), 0, s, counts1, L.parts, starts1, cursors1,
-                       static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(jl_offsets1_kernel, dim3(L.k1), dim3(kJlThreads), 0, s, counts1, starts0, L.k1, L.k2, starts1,
+                       cursors1);
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
                        L.parts, L.k1, L.k2, cursors1, k_b, r_b);
     pk = k_b;
