@@ -27,6 +27,7 @@ SIGNATURES = {
     "dbhip_groupby_sum_u32": (_int, [_vp, _vp, _sz, _u32, _vp, _vp, _sz, _vp]),
     "dbhip_join_workspace_bytes": (_sz, [_sz]),
     "dbhip_join_build_u32": (_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "dbhip_join_build_pairs_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_probe_u32": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dbhip_ujoin_workspace_bytes": (_sz, [_sz]),
     "dbhip_ujoin_build_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),

@@ -157,6 +157,7 @@ __device__ __forceinline__ unsigned find_slot(const unsigned *__restrict__ keys,
 // ---- 4a build: ids[pos[slot]++] = build row (pos ends up as the END offset of every slot) --------
 __global__ __launch_bounds__(kJoinThreads) void join_fill_ids_kernel(const unsigned *__restrict__ build,
                                                                      size_t n,
+                                                                     const unsigned *__restrict__ row_ids,
                                                                      const unsigned *__restrict__ keys,
                                                                      unsigned *pos, unsigned mask,
                                                                      unsigned *__restrict__ ids) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kJoinThreads) void join_fill_ids_kernel(const unsig
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride) {
     bool found;
     const unsigned s = find_slot(keys, build[i], mask, &found);
-    if (found) ids[atomicAdd(&pos[s], 1u)] = static_cast<unsigned>(i);
+    if (found) ids[atomicAdd(&pos[s], 1u)] = row_ids ? row_ids[i] : static_cast<unsigned>(i);
   }
 }
 
@@ -250,8 +251,10 @@ extern "C" size_t dbhip_join_workspace_bytes(size_t n_build) {
   return jl_use(n_build) ? jl_layout(n_build).total : join_layout(n_build).total;
 }
 
-extern "C" int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids,
-                                    void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
+namespace {
+// shared by dbhip_join_build_u32 (row ids = 0..n-1) and dbhip_join_build_pairs_u32 (caller's row ids)
+int join_build_impl(const uint32_t *build_keys, const uint32_t *row_ids, size_t n_build, uint32_t *ids,
+                    void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (n_build && (!build_keys || !ids)) return DBHIP_EINVAL;
   if (n_build >= 0x7FFFFFFFull) return DBHIP_EINVAL;  // 32-bit ids / positions
   if (!ws_ok(workspace, workspace_bytes, dbhip_join_workspace_bytes(n_build))) return DBHIP_EWORKSPACE;
@@ -259,7 +262,7 @@ extern "C" int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, 
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
   if (jl_use(n_build))  // large build sides: radix-partitioned, LDS-resident sub-tables (join_lds.hip)
-    return join_lds_build(build_keys, nullptr, n_build, ids, workspace, s, dev);
+    return join_lds_build(build_keys, row_ids, n_build, ids, workspace, s, dev);
   const JoinLayout L = join_layout(n_build);
   char *base = static_cast<char *>(workspace);
   JoinHeader *hdr = reinterpret_cast<JoinHeader *>(base);
@@ -288,8 +291,21 @@ extern "C" int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, 
                      dim3(kJoinThreads), 0, s, cnt, pos, L.cap, hdr, gran, tiles);
   if (n_build)
     hipLaunchKernelGGL(join_fill_ids_kernel, dim3(grid_for(n_build, dev, 8)), dim3(kJoinThreads), 0, s,
-                       build_keys, n_build, keys, pos, mask, ids);
+                       build_keys, n_build, row_ids, keys, pos, mask, ids);
   return launch_status();
+}
+}  // namespace
+
+extern "C" int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids,
+                                    void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
+  return join_build_impl(build_keys, nullptr, n_build, ids, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dbhip_join_build_pairs_u32(const uint32_t *build_keys, const uint32_t *build_row_ids,
+                                          size_t n_build, uint32_t *ids, void *workspace,
+                                          size_t workspace_bytes, dbhip_stream_t stream) {
+  if (n_build && !build_row_ids) return DBHIP_EINVAL;
+  return join_build_impl(build_keys, build_row_ids, n_build, ids, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void *workspace,

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__
 // One workgroup, thread b owns bucket b (k1 <= 1024).
 __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long long *__restrict__ counts_g,
                                                            unsigned k1, unsigned long long *cursors_g,
-                                                           unsigned long long *starts, unsigned long long *tile_starts) {
+                                                           unsigned long long *starts, unsigned long long *tile_starts,
+                                                           unsigned long long *totals_out) {
   __shared__ unsigned long long s_tot[1024], s_start[1025], s_tstart[1025];
   const unsigned b = threadIdx.x;
   unsigned long long tot = 0;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long l
   if (b < k1) {
     starts[b] = s_start[b];
     tile_starts[b] = s_tstart[b];
+    if (totals_out) totals_out[b] = s_tot[b];
     unsigned long long run = s_start[b];
     for (unsigned g = 0; g < kJlGroups; ++g) {
       cursors_g[static_cast<size_t>(g) * k1 + b] = run;
@@ -215,7 +217,8 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
 
 // level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
 __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
-                                                                 const unsigned *__restrict__ row_ids, size_t n,
+                                                                 const unsigned *__restrict__ row_ids,
+                                                                 unsigned long long first_row, size_t n,
                                                                  unsigned parts, unsigned k2_shift, unsigned k1,
                                                                  unsigned long long *cursors,
                                                                  unsigned *__restrict__ out_keys,
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
       const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
       const bool valid = idx < n;
       key[j] = valid ? keys[idx] : 0u;
-      rid[j] = valid ? (row_ids ? row_ids[idx] : static_cast<unsigned>(idx)) : 0u;
+      rid[j] = valid ? (row_ids ? row_ids[idx] : static_cast<unsigned>(first_row + idx)) : 0u;
       dest[j] = valid ? jl_pid(key[j], parts) >> k2_shift : k1;
     }
     const size_t group = tile / jl_tiles_per_group(n);  // this tile bumps only its group's cursors
@@ -436,12 +439,13 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const size_t lds0 = jl_scatter_lds_bytes(L.k1);
   hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), L.k1 * sizeof(unsigned),
                      s, build_keys, n, L.parts, k2_shift, L.k1, counts0);
-  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, cursors0, starts0, tstarts0);
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, cursors0, starts0, tstarts0,
+                     static_cast<unsigned long long *>(nullptr));
   {
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
     hipLaunchKernelGGL(jl_scatter0_kernel, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
-                       lds0, s, build_keys, row_ids, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
+                       lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
   }
   const unsigned *pk = k_a, *pr = r_a;
   const unsigned long long *pstarts = starts0;
@@ -473,6 +477,37 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
   const u32x4 *table = reinterpret_cast<const u32x4 *>(static_cast<const char *>(workspace) + L.table_off);
   hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
                      table, L.parts, out_pos, out_cnt);
+  return launch_status();
+}
+
+// ---- stand-alone level-0 partition (multi-GPU join: bucket = destination rank) ------------------------
+size_t jl_partition_workspace_bytes(unsigned parts) {
+  return align_up(kWsHeader + sizeof(unsigned long long) * ((2 * static_cast<size_t>(kJlGroups) + 2) * parts + 2),
+                  kWsAlign);
+}
+
+int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, unsigned parts, unsigned *out_keys,
+                 unsigned *out_rids, unsigned long long *out_counts, void *workspace, hipStream_t s,
+                 const DeviceInfo &dev) {
+  char *base = static_cast<char *>(workspace);
+  unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + kWsHeader);
+  unsigned long long *counts0 = meta;
+  unsigned long long *cursors0 = counts0 + static_cast<size_t>(kJlGroups) * parts;
+  unsigned long long *starts0 = cursors0 + static_cast<size_t>(kJlGroups) * parts;
+  unsigned long long *tstarts0 = starts0 + parts + 1;
+  hipError_t e = hipMemsetAsync(base, 0, jl_partition_workspace_bytes(parts), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), parts * sizeof(unsigned), s,
+                     keys, n, parts, 0u, parts, counts0);
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, parts, cursors0, starts0, tstarts0,
+                     out_counts);
+  if (n) {
+    const size_t tiles = (n + kJlTile - 1) / kJlTile;
+    const size_t cap = static_cast<size_t>(dev.cus) * 8;
+    hipLaunchKernelGGL(jl_scatter0_kernel, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
+                       jl_scatter_lds_bytes(parts), s, keys, static_cast<const unsigned *>(nullptr), first_row, n, parts,
+                       0u, parts, cursors0, out_keys, out_rids);
+  }
   return launch_status();
 }
 

@@ -171,10 +171,17 @@ class HashJoin:
         self.pos = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
         self.cnt = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
 
-    def build(self, build_keys: torch.Tensor) -> None:
+    def build(self, build_keys: torch.Tensor, row_ids: torch.Tensor | None = None) -> None:
+        """row_ids given: the id buffer receives those values (e.g. global row ids) instead of 0..n-1"""
         _need(build_keys, torch.int32, "build_keys")
-        _capi.check(_capi.lib().dbhip_join_build_u32(build_keys.data_ptr(), self.nb, self.ids.data_ptr(),
-                                                     self.ws.data_ptr(), self.ws_bytes, _stream()), "join_build_u32")
+        if row_ids is None:
+            _capi.check(_capi.lib().dbhip_join_build_u32(build_keys.data_ptr(), self.nb, self.ids.data_ptr(),
+                                                         self.ws.data_ptr(), self.ws_bytes, _stream()), "join_build_u32")
+        else:
+            _need(row_ids, torch.int32, "row_ids")
+            _capi.check(_capi.lib().dbhip_join_build_pairs_u32(build_keys.data_ptr(), row_ids.data_ptr(), self.nb,
+                                                               self.ids.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                               _stream()), "join_build_pairs_u32")
 
     def probe(self, probe_keys: torch.Tensor) -> None:
         _need(probe_keys, torch.int32, "probe_keys")

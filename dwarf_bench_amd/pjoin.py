@@ -8,8 +8,8 @@ Per rank, with local shards of the build (R) and probe (S) key columns and their
   3. exchange   all_to_all of the pairs (RCCL: every GPU sends 1/P of its rows to each peer, one peer per
                 xGMI link, all links busy at once) — keys and row ids of one relation travel as one
                 int32 [n, 2]... two columns, one collective per column;
-  4. local join dwarf 4a on the received pairs (dbhip_join_build_u32 / dbhip_join_probe_u32), build-row
-                indices turned into GLOBAL row ids with dbhip_gather_u32.
+  4. local join dwarf 4a on the received pairs (dbhip_join_build_pairs_u32 / dbhip_join_probe_u32): the id
+                buffer holds GLOBAL build row ids.
 Results stay sharded by key hash: per rank (probe global row id, offset, count) + the id buffer.
 
 The compute steps go through a small backend object so that the orchestration (split sizes, collectives,
@@ -31,16 +31,13 @@ class HipBackend:
         from . import ops
         return ops.partition_by_hash(keys, first_row_id, parts)
 
-    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor):
+    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None):
+        """-> pos, cnt, ids; ids hold build_row_ids values when given (global row ids), else local indices"""
         from . import ops
         plan = ops.HashJoin(build_keys.numel(), probe_keys.numel(), build_keys.device)
-        plan.build(build_keys)
+        plan.build(build_keys, build_row_ids)
         plan.probe(probe_keys)
-        return plan.result()  # pos, cnt, ids (local build indices)
-
-    def gather(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        from . import ops
-        return ops.gather_u32(table, idx)
+        return plan.result()
 
 
 @dataclass
@@ -99,8 +96,7 @@ def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_f
     sk_in = _exchange(sk, send_h[1], recv_h[1], group)
     sr_in = _exchange(sr, send_h[1], recv_h[1], group)
 
-    pos, cnt, ids_local = backend.local_join(rk_in, sk_in)
-    ids_global = backend.gather(rr_in, ids_local)
+    pos, cnt, ids_global = backend.local_join(rk_in, sk_in, rr_in)
     sent = int(sum(send_h[0]) - send_h[0][rank] + sum(send_h[1]) - send_h[1][rank])
     return PartitionedJoinResult(sr_in, pos, cnt, ids_global, sent, rk_in.numel(), sk_in.numel())
 

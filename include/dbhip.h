@@ -111,6 +111,11 @@ int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n, 
 size_t dbhip_join_workspace_bytes(size_t n_build);
 int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
+/* same build over (key, row id) pairs: ids[] receives build_row_ids[] values instead of 0..n-1
+ * (the partitioned multi-GPU join builds on received pairs carrying GLOBAL row ids) */
+int dbhip_join_build_pairs_u32(const uint32_t *build_keys, const uint32_t *build_row_ids, size_t n_build,
+                               uint32_t *ids, void *workspace, size_t workspace_bytes,
+                               dbhip_stream_t stream);
 int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void *workspace,
                          size_t n_build, uint32_t *out_pos, uint32_t *out_count,
                          dbhip_stream_t stream);

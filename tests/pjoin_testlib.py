@@ -33,15 +33,14 @@ class OracleBackend:
         return (torch.from_numpy(k[order].view(np.int32).copy()), torch.from_numpy(rid[order].view(np.int32).copy()),
                 torch.from_numpy(counts))
 
-    def local_join(self, build_keys, probe_keys):
+    def local_join(self, build_keys, probe_keys, build_row_ids=None):
         b = build_keys.numpy().view(np.uint32)
         p = probe_keys.numpy().view(np.uint32)
         pos, cnt, ids = po.join_omnisci(b, p)
+        if build_row_ids is not None:
+            ids = build_row_ids.numpy().view(np.uint32)[ids.astype(np.int64)]
         t = lambda a: torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
         return t(pos), t(cnt), t(ids)
-
-    def gather(self, table, idx):
-        return table[idx.to(torch.int64)]
 
 
 def check_global(results, build_all: np.ndarray, probe_all: np.ndarray):
