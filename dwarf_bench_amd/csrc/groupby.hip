@@ -12,8 +12,8 @@
 //                 never collides).  A table holds at most 32768 groups (128 KiB of the 160 KiB LDS):
 //                 for more groups the key space is cut into R ranges and workgroup (x, r) aggregates
 //                 only range r of chunk x — partner workgroups read the same rows at about the same
-//                 time, so the second read is served by L2 / Infinity Cache, not HBM.  Tiny group
-//                 counts replicate the table across lanes to spread same-address LDS atomics.
+//                 time, so the second read is served by L2 / Infinity Cache, not HBM.  Few groups:
+//                 the table is replicated across lanes (odd stride) to spread same-address ds_add.
 //   gb_reduce     sums the per-workgroup partial tables into output[] (plain coalesced loads, no
 //                 global atomics: memory-side atomics are ~5x slower than stores on this chip).
 //
@@ -25,8 +25,6 @@ namespace {
 
 constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table
 constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table is large
-constexpr int kGbSmallThreads = 256;
-constexpr int kGbSmallLdsWords = 8192;  // <= 32 KiB tables run 256-thread workgroups, 4 per CU
 constexpr int kGbVecPerIter = 2;        // uint4 key + uint4 val loads in flight per lane per step
 
 struct GbHeader {
@@ -38,7 +36,8 @@ static_assert(sizeof(GbHeader) == kWsHeader, "workspace header size");
 struct GbGeometry {
   unsigned ranges;       // R key ranges
   unsigned range_groups; // groups per range (last may be short)
-  unsigned replicas;     // lane-replicated copies of the table (tiny group counts)
+  unsigned replicas;     // lane-replicated copies of the table (few groups)
+  unsigned rep_stride;   // words between copies (odd when replicated)
   unsigned threads;      // workgroup size
   unsigned chunk_slots;  // workgroups per range = partial tables per range
   unsigned lds_words;
@@ -50,22 +49,22 @@ inline GbGeometry gb_geometry(uint32_t groups, int cus) {
   if (g.ranges == 0) g.ranges = 1;
   g.range_groups = (groups + g.ranges - 1) / g.ranges;
   if (g.range_groups == 0) g.range_groups = 1;
-  g.replicas = 1;
-  if (g.range_groups <= 256) {  // spread same-address LDS atomics over lane-private copies
-    g.replicas = 32;
-    while (g.replicas > 1 && g.range_groups * g.replicas > kGbSmallLdsWords) g.replicas /= 2;
-  }
-  g.lds_words = g.range_groups * g.replicas;
-  const bool small = g.lds_words <= kGbSmallLdsWords;
-  g.threads = small ? kGbSmallThreads : kGbBigThreads;
-  const unsigned per_cu = small ? 4u : 1u;
-  unsigned total = static_cast<unsigned>(cus) * per_cu;
+  // Few groups: same-address ds_add serialises, so the table is replicated and lane l adds into copy
+  // l % replicas.  The copies are an ODD number of words apart: a stride that is a multiple of the 32
+  // LDS banks (64 groups!) would put the same key of every copy on one bank and undo the spreading.
+  g.replicas = 32;
+  while (g.replicas > 1 && (g.range_groups | 1u) * g.replicas > static_cast<unsigned>(kGbMaxLdsGroups)) g.replicas /= 2;
+  g.rep_stride = g.replicas > 1 ? (g.range_groups | 1u) : g.range_groups;
+  g.lds_words = g.rep_stride * g.replicas;
+  // one 16-wave workgroup per CU for every table size: a few hundred partial tables keep gb_reduce short
+  g.threads = kGbBigThreads;
+  unsigned total = static_cast<unsigned>(cus);
   g.chunk_slots = total / g.ranges;
   if (g.chunk_slots == 0) g.chunk_slots = 1;
   return g;
 }
 
-template <int THREADS>
+template <int THREADS, bool kShared>
 __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
     const u32x4 *__restrict__ keys4, const u32x4 *__restrict__ vals4, const unsigned *__restrict__ keys,
     const unsigned *__restrict__ vals, size_t n, unsigned groups, GbGeometry geo,
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
   const unsigned lo = range * geo.range_groups;
   const unsigned hi_excl = lo + geo.range_groups < groups ? lo + geo.range_groups : groups;
   const unsigned span = hi_excl > lo ? hi_excl - lo : 0;
-  const unsigned rep_off = (tid % geo.replicas) * geo.range_groups;
+  const unsigned rep_off = (tid % geo.replicas) * geo.rep_stride;
 
   for (unsigned i = tid; i < geo.lds_words; i += THREADS) s_table[i] = 0;
   __syncthreads();
@@ -100,8 +99,13 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
     for (int u = 0; u < kGbVecPerIter; ++u) {
       const size_t i = base + static_cast<size_t>(u) * THREADS + tid;
       if (i < n4) {
-        k[u] = __builtin_nontemporal_load(keys4 + i);
-        v[u] = __builtin_nontemporal_load(vals4 + i);
+        if (kShared) {  // rows are read again by the partner workgroup: let them live in L2
+          k[u] = keys4[i];
+          v[u] = vals4[i];
+        } else {  // read once
+          k[u] = __builtin_nontemporal_load(keys4 + i);
+          v[u] = __builtin_nontemporal_load(vals4 + i);
+        }
       } else {
         k[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         v[u] = u32x4{0u, 0u, 0u, 0u};
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
   unsigned *dst = partials + (static_cast<size_t>(range) * geo.chunk_slots + slot) * geo.range_groups;
   for (unsigned g = tid; g < geo.range_groups; g += THREADS) {
     unsigned sum = 0;
-    for (unsigned r = 0; r < geo.replicas; ++r) sum += s_table[r * geo.range_groups + g];
+    for (unsigned r = 0; r < geo.replicas; ++r) sum += s_table[r * geo.rep_stride + g];
     dst[g] = sum;
   }
 }
@@ -201,15 +205,18 @@ extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals,
   const unsigned grid = geo.ranges * geo.chunk_slots;
   const size_t lds = static_cast<size_t>(geo.lds_words) * sizeof(unsigned);
   const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys), *v4 = reinterpret_cast<const u32x4 *>(vals);
-  if (geo.threads == kGbBigThreads) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kGbMaxLdsGroups * 4);
+  if (geo.ranges > 2) {  // measured: plain (L2-allocating) loads win from 4 readers per row on, nt below
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (kGbMaxLdsGroups + 32) * 4);
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
+    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads, true>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
                        v4, keys, vals, n, groups, geo, partials, hdr);
   } else {
-    hipLaunchKernelGGL((gb_aggregate_kernel<kGbSmallThreads>), dim3(grid), dim3(kGbSmallThreads), lds, s,
-                       k4, v4, keys, vals, n, groups, geo, partials, hdr);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (kGbMaxLdsGroups + 32) * 4);
+    if (e != hipSuccess) return static_cast<int>(e);
+    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads, false>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
+                       v4, keys, vals, n, groups, geo, partials, hdr);
   }
   hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, s, partials, geo, groups,
                      out);

@@ -1,26 +1,32 @@
-// radix.hip — dwarf 2: LSD radix sort of 32-bit keys for gfx950, one sweep per digit.
+// radix.hip — dwarf 2: LSD radix sort of 32-bit keys for gfx950.
 //
 // Replaces oneDPL's std::sort(device_policy) behind Radix/RadixCuda (dpl_wrapper.hpp:35-39 <-
 // sort/radix.cpp:34); result identical to std::sort (sort/radix.cpp:8-12).
 //
 // Structure (digit width BITS = 8 tuned, 4 = the configuration named in BASELINE.json):
-//   1. rs_histogram   one read of the keys: global digit totals for EVERY pass (LDS histograms per
-//                     workgroup, one coalesced atomic flush per workgroup).
-//   2. rs_plan        one workgroup: per pass the exclusive digit bases, and which passes are skipped
-//                     because their digit is constant over the whole input (e.g. keys in [1,10000]
-//                     skip the two upper bytes); fixes the ping-pong parity of every pass.
-//   3. rs_sweep x P   ONE kernel per executed pass: a persistent grid walks 4096-key tiles; each wave
-//                     ranks its 1024 keys stably with wave64 match masks (BITS ballots per key,
-//                     v_mbcnt for the lane rank, wave-private LDS digit counters), the tile is
-//                     re-ordered by digit through LDS, per-digit tile offsets come from a decoupled
-//                     look-back over 4-byte {state,count} granules (lookback.hpp), and the tile is
-//                     written out in digit order so consecutive lanes hit consecutive addresses.
-//   4. rs_finalize    copies tmp -> keys when an odd number of passes ran.
+//   1. rs_histogram      one read of the keys: global digit totals for EVERY pass (LDS histograms per
+//                        workgroup, one coalesced atomic flush per workgroup).
+//   2. rs_plan           one workgroup: per pass the exclusive digit bases, and which passes are skipped
+//                        because their digit is constant over the whole input (e.g. keys in [1,10000]
+//                        skip the two upper bytes); fixes the ping-pong parity of every pass.
+//   3. per executed pass, three kernels over CHUNKS of consecutive 4096-key tiles, with no communication
+//      between workgroups inside a kernel:
+//        rs_chunk_hist     digit counts of every chunk (LDS histogram) -> counts[digit][chunk]
+//        rs_chunk_scan     one workgroup per digit: exclusive scan of its row + the digit base
+//        rs_chunk_scatter  one workgroup per chunk, tile by tile: each wave ranks its 1024 keys stably
+//                          with wave64 match masks (BITS ballots per key — CDNA has no match
+//                          instruction —, v_mbcnt for the lane rank, wave-private LDS digit counters),
+//                          the tile is re-ordered by digit through LDS and written out in digit order,
+//                          so consecutive lanes hit consecutive addresses; the chunk's running
+//                          per-digit offsets live in registers of the digit-owner threads.
+//      (A single-pass Onesweep with decoupled look-back was measured first: 106 us per 8-bit pass at
+//      2^24 keys, dominated by look-back waits between tiles in flight; same finding as in scan.hip.)
+//   4. rs_finalize       copies tmp -> keys when an odd number of passes ran.
 //
-// Bytes: 4N (histogram) + P * 8N (sweeps), P <= 32/BITS; everything between passes stays device-side
-// (no host round trip: skipped passes return at once on a device-side flag).
+// Bytes: 4N (histogram) + P * 12N (chunk histogram read + scatter read/write), P <= 32/BITS; at 2^24
+// keys both ping-pong buffers (128 MiB) live in the 256 MiB Infinity Cache.  Everything between passes
+// stays device-side (skipped passes return at once on a device-side flag, no host round trip).
 #include "dbhip_common.hpp"
-#include "lookback.hpp"
 
 namespace dbhip {
 namespace {
@@ -32,9 +38,10 @@ constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wav
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 4096 keys
 constexpr int kRsMaxPasses = 8;
 constexpr int kRsMaxRadix = 256;
+constexpr size_t kRsTargetChunks = 2048;         // chunks per pass (>= 8 per CU for balance)
 
 struct RsPass {
-  unsigned skip;        // digit constant over the input: the sweep returns immediately
+  unsigned skip;        // digit constant over the input: the pass's kernels return immediately
   unsigned src_is_tmp;  // which buffer holds the keys when this pass starts
 };
 struct RsHeader {
@@ -46,10 +53,23 @@ struct RsHeader {
 };
 static_assert(sizeof(RsHeader) == kWsHeader, "workspace header size");
 
-// workspace: header | totals[8][256] | bases[8][256] | granules[passes][tiles][radix]
+// workspace: header | totals[8][256] | bases[8][256] | counts[radix][chunks]
 constexpr size_t kRsTotalsOff = kWsHeader;
 constexpr size_t kRsBasesOff = kRsTotalsOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
-constexpr size_t kRsGranulesOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
+constexpr size_t kRsCountsOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
+
+struct RsGeometry {
+  size_t tiles, tiles_per_chunk, chunks;
+};
+inline RsGeometry rs_geometry(size_t n) {
+  RsGeometry g;
+  g.tiles = (n + kRsTile - 1) / kRsTile;
+  g.tiles_per_chunk = (g.tiles + kRsTargetChunks - 1) / kRsTargetChunks;
+  if (g.tiles_per_chunk == 0) g.tiles_per_chunk = 1;
+  g.chunks = (g.tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
+  if (g.chunks == 0) g.chunks = 1;
+  return g;
+}
 
 // lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA)
 template <int BITS>
@@ -75,15 +95,27 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
   __syncthreads();
   const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
   const size_t n4 = n / 4;
-  const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
   for (size_t i = static_cast<size_t>(blockIdx.x) * kRsThreads + threadIdx.x; i < n4; i += stride) {
-    const uint4 v = k4[i];
+    const u32x4 v = k4[i];
     const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int p = 0; p < kPasses; ++p) {
+      // a digit that is the same in the whole wave (the upper bytes of small keys: the reference's
+      // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
+      const unsigned d0 = (k[0] >> (p * BITS)) & (kRadix - 1);
+      const unsigned first = __builtin_amdgcn_readfirstlane(d0);
+      const bool same = ((k[0] >> (p * BITS)) & (kRadix - 1)) == first && ((k[1] >> (p * BITS)) & (kRadix - 1)) == first &&
+                        ((k[2] >> (p * BITS)) & (kRadix - 1)) == first && ((k[3] >> (p * BITS)) & (kRadix - 1)) == first;
+      const unsigned long long active = __ballot(true);
+      if (__ballot(same) == active) {
+        if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
+          atomicAdd(&s_hist[p * kRadix + first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
+      } else {
 #pragma unroll
-      for (int p = 0; p < kPasses; ++p)
-        atomicAdd(&s_hist[p * kRadix + ((k[c] >> (p * BITS)) & (kRadix - 1))], 1u);
+        for (int c = 0; c < 4; ++c) atomicAdd(&s_hist[p * kRadix + ((k[c] >> (p * BITS)) & (kRadix - 1))], 1u);
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
     const unsigned k = keys[n4 * 4 + threadIdx.x] ^ xor_mask;
@@ -131,12 +163,74 @@ __global__ __launch_bounds__(kRsThreads) void rs_plan_kernel(size_t n, RsHeader 
   }
 }
 
+// ---- per pass, kernel 1: digit counts of every chunk -------------------------------------------------
 template <int BITS>
-__global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys, unsigned *tmp, size_t n,
-                                                              int pass, unsigned xor_mask,
-                                                              RsHeader *hdr,
-                                                              const unsigned *__restrict__ bases,
-                                                              unsigned *granules, size_t num_tiles) {
+__global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigned *keys, const unsigned *tmp,
+                                                                   size_t n, int pass, unsigned xor_mask,
+                                                                   const RsHeader *hdr, unsigned *counts,
+                                                                   size_t tiles_per_chunk, size_t num_chunks) {
+  constexpr int kRadix = 1 << BITS;
+  __shared__ unsigned s_hist[kRadix];
+  const RsPass plan = hdr->pass[pass];
+  if (plan.skip) return;
+  const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
+  const int shift = pass * BITS;
+  const size_t chunk = blockIdx.x;
+  const size_t lo = chunk * tiles_per_chunk * kRsTile;
+  size_t hi = lo + tiles_per_chunk * kRsTile;
+  hi = hi < n ? hi : n;
+  for (int i = threadIdx.x; i < kRadix; i += kRsThreads) s_hist[i] = 0;
+  __syncthreads();
+  // chunk starts are multiples of 4096 keys: 16-byte loads are aligned
+  const size_t n4 = (hi - lo) / 4;
+  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
+  for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
+    const u32x4 v = k4[i];
+    atomicAdd(&s_hist[((v.x ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+    atomicAdd(&s_hist[((v.y ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+    atomicAdd(&s_hist[((v.z ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+    atomicAdd(&s_hist[((v.w ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+  }
+  for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads)
+    atomicAdd(&s_hist[((src[i] ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+  __syncthreads();
+  for (int d = threadIdx.x; d < kRadix; d += kRsThreads) counts[static_cast<size_t>(d) * num_chunks + chunk] = s_hist[d];
+}
+
+// ---- per pass, kernel 2: counts[d][*] -> global start of digit d in every chunk ------------------------
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, const RsHeader *hdr,
+                                                                   const unsigned *__restrict__ bases,
+                                                                   unsigned *counts, size_t num_chunks) {
+  __shared__ unsigned s_wsum[kRsWaves];
+  __shared__ unsigned s_carry;
+  if (hdr->pass[pass].skip) return;
+  const unsigned d = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  unsigned *row = counts + static_cast<size_t>(d) * num_chunks;
+  if (tid == 0) s_carry = bases[pass * kRsMaxRadix + d];
+  __syncthreads();
+  for (size_t base = 0; base < num_chunks; base += kRsThreads) {
+    const size_t i = base + tid;
+    const unsigned v = i < num_chunks ? row[i] : 0u;
+    const unsigned incl = wave_inclusive_scan(v);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned off = s_carry;
+    for (unsigned w = 0; w < wave; ++w) off += s_wsum[w];
+    if (i < num_chunks) row[i] = off + incl - v;
+    __syncthreads();
+    if (tid == kRsThreads - 1) s_carry = off + incl;
+    __syncthreads();
+  }
+}
+
+// ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads, 4) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
+                                                                         int pass, unsigned xor_mask,
+                                                                         const RsHeader *hdr,
+                                                                         const unsigned *__restrict__ offsets,
+                                                                         size_t tiles_per_chunk, size_t num_chunks) {
   constexpr int kRadix = 1 << BITS;
   __shared__ unsigned s_cnt[kRsWaves][kRadix];  // per-wave digit counts, then wave-exclusive offsets
   __shared__ unsigned s_dexcl[kRadix];          // tile-local exclusive offset of each digit
@@ -149,16 +243,23 @@ __global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys,
   const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
   unsigned *__restrict__ dst = plan.src_is_tmp ? keys : tmp;
   const int shift = pass * BITS;
-  const unsigned *dbase = bases + pass * kRsMaxRadix;
 
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const unsigned long long lanes_lt = (1ull << lane) - 1ull;
+  const size_t chunk = blockIdx.x;
+  const size_t first_tile = chunk * tiles_per_chunk;
+  const size_t total_tiles = (n + kRsTile - 1) / kRsTile;
+  size_t last_tile = first_tile + tiles_per_chunk;
+  last_tile = last_tile < total_tiles ? last_tile : total_tiles;
+  // digit owners keep the chunk's running global offset of their digit in a register
+  unsigned running = tid < kRadix ? offsets[static_cast<size_t>(tid) * num_chunks + chunk] : 0u;
 
-  for (size_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+  const unsigned wave_first = wave * kRsWaveKeys + lane;
+  // (prefetching the next tile's keys into a second register set was measured: it needs 3 waves/SIMD
+  //  instead of 4 to avoid spills and came out 7 % slower at 2^24 keys)
+  for (size_t tile = first_tile; tile < last_tile; ++tile) {
     const size_t tile_base = tile * kRsTile;
-    const unsigned valid_in_tile =
-        static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
-    const unsigned wave_first = wave * kRsWaveKeys + lane;
+    const unsigned valid_in_tile = static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
 
     unsigned key[kRsKpt];
 #pragma unroll
@@ -183,7 +284,7 @@ __global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys,
     }
     __syncthreads();
 
-    // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals, granule
+    // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals
     unsigned tile_count = 0;
     if (tid < kRadix) {
 #pragma unroll
@@ -192,15 +293,17 @@ __global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys,
         s_cnt[w][tid] = tile_count;
         tile_count += c;
       }
-      st_agent(granules + tile * kRadix + tid,
-               (tile == 0 ? kLb32Inclusive : kLb32Aggregate) | tile_count);
     }
     const unsigned incl = wave_inclusive_scan(tile_count);
     if (lane == kWave - 1) s_wsum[wave] = incl;
     __syncthreads();
     unsigned dexcl = incl - tile_count;
     for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
-    if (tid < kRadix) s_dexcl[tid] = dexcl;
+    if (tid < kRadix) {
+      s_dexcl[tid] = dexcl;
+      s_goff[tid] = running - dexcl;
+      running += tile_count;
+    }
     __syncthreads();
 
     // ---- re-order the tile by digit in LDS
@@ -210,15 +313,6 @@ __global__ __launch_bounds__(kRsThreads, 4) void rs_sweep_kernel(unsigned *keys,
         const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
         s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
       }
-    }
-    // ---- global offset of each digit of this tile (look-back latency overlaps the LDS writes)
-    if (tid < kRadix) {
-      unsigned excl = 0;
-      if (tile != 0) {
-        excl = lookback_column32(granules, tile, kRadix, tid, &hdr->status);
-        st_agent(granules + tile * kRadix + tid, kLb32Inclusive | ((excl + tile_count) & kLb32Value));
-      }
-      s_goff[tid] = dbase[tid] + excl - dexcl;
     }
     __syncthreads();
 
@@ -242,20 +336,11 @@ __global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__res
   if (!hdr->final_in_tmp) return;
   const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
   const size_t n4 = n / 4;
-  const uint4 *s4 = reinterpret_cast<const uint4 *>(tmp);
-  uint4 *d4 = reinterpret_cast<uint4 *>(keys);
+  const u32x4 *s4 = reinterpret_cast<const u32x4 *>(tmp);
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(keys);
   for (size_t i = static_cast<size_t>(blockIdx.x) * kRsThreads + threadIdx.x; i < n4; i += stride)
     d4[i] = s4[i];
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) keys[n4 * 4 + threadIdx.x] = tmp[n4 * 4 + threadIdx.x];
-}
-
-inline int rs_blocks_per_cu() {
-  static const int v = [] {
-    const char *e = getenv("DBHIP_SORT_BLOCKS_PER_CU");
-    int x = e ? atoi(e) : 0;
-    return (x >= 1 && x <= 6) ? x : 4;
-  }();
-  return v;
 }
 
 template <int BITS>
@@ -263,15 +348,14 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
                     hipStream_t s, const DeviceInfo &dev) {
   constexpr int kPasses = 32 / BITS;
   constexpr int kRadix = 1 << BITS;
-  const size_t tiles = (n + kRsTile - 1) / kRsTile;
+  const RsGeometry g = rs_geometry(n);
   char *base = static_cast<char *>(workspace);
   RsHeader *hdr = reinterpret_cast<RsHeader *>(base);
   unsigned *totals = reinterpret_cast<unsigned *>(base + kRsTotalsOff);
   unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
-  unsigned *granules = reinterpret_cast<unsigned *>(base + kRsGranulesOff);
-  const size_t gran_bytes = sizeof(unsigned) * kPasses * tiles * kRadix;
+  unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
 
-  hipError_t e = hipMemsetAsync(workspace, 0, kRsGranulesOff + gran_bytes, s);
+  hipError_t e = hipMemsetAsync(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
   if (e != hipSuccess) return static_cast<int>(e);
 
   const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
@@ -280,13 +364,15 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hgrid), dim3(kRsThreads), 0, s, keys, n,
                      xor_mask, totals);
   hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
-  const size_t scap = static_cast<size_t>(dev.cus) *
-                      resident_blocks_per_cu(rs_sweep_kernel<BITS>, kRsThreads, 0, rs_blocks_per_cu());
-  const unsigned sgrid = static_cast<unsigned>(tiles < scap ? tiles : scap);
-  for (int p = 0; p < kPasses; ++p)
-    hipLaunchKernelGGL((rs_sweep_kernel<BITS>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
-                       xor_mask, hdr, bases, granules + static_cast<size_t>(p) * tiles * kRadix,
-                       tiles);
+  const unsigned cgrid = static_cast<unsigned>(g.chunks);
+  for (int p = 0; p < kPasses; ++p) {
+    hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
+                       hdr, counts, g.tiles_per_chunk, g.chunks);
+    hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
+                       g.chunks);
+    hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                       xor_mask, hdr, counts, g.tiles_per_chunk, g.chunks);
+  }
   hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
   return launch_status();
 }
@@ -294,7 +380,7 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
 int radix_sort_entry(unsigned *keys, unsigned *tmp, size_t n, int radix_bits, unsigned xor_mask,
                      void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (radix_bits != 4 && radix_bits != 8) return DBHIP_EINVAL;
-  if (n >= (1ull << 30)) return DBHIP_EINVAL;  // 30-bit granule values
+  if (n >= (1ull << 32)) return DBHIP_EINVAL;  // 32-bit offsets
   if (n == 0) return DBHIP_OK;
   if (!keys || !tmp) return DBHIP_EINVAL;
   if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) return DBHIP_EINVAL;
@@ -314,9 +400,9 @@ using namespace dbhip;
 
 extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
   if (radix_bits != 4 && radix_bits != 8) return 0;
-  const size_t tiles = (n + kRsTile - 1) / kRsTile;
-  const size_t passes = 32 / radix_bits, radix = static_cast<size_t>(1) << radix_bits;
-  return align_up(kRsGranulesOff + sizeof(unsigned) * passes * (tiles ? tiles : 1) * radix, kWsAlign);
+  const RsGeometry g = rs_geometry(n);
+  const size_t radix = static_cast<size_t>(1) << radix_bits;
+  return align_up(kRsCountsOff + sizeof(unsigned) * radix * g.chunks, kWsAlign);
 }
 
 extern "C" int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits,
