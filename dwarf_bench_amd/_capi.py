@@ -25,6 +25,8 @@ SIGNATURES = {
     "dbhip_radix_sort_i32": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp]),
     "dbhip_groupby_sum_u32_workspace_bytes": (_sz, [_sz, _u32]),
     "dbhip_groupby_sum_u32": (_int, [_vp, _vp, _sz, _u32, _vp, _vp, _sz, _vp]),
+    "dbhip_groupby_partial_u32": (_int, [_vp, _vp, _sz, _u32, _u32, _vp, _sz, _vp]),
+    "dbhip_groupby_merge_u32": (_int, [_u32, _u32, _vp, _vp, _vp]),
     "dbhip_join_workspace_bytes": (_sz, [_sz]),
     "dbhip_join_build_u32": (_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_build_pairs_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
@@ -32,6 +34,10 @@ SIGNATURES = {
     "dbhip_ujoin_workspace_bytes": (_sz, [_sz]),
     "dbhip_ujoin_build_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "dbhip_ujoin_probe_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dbhip_bitmask_table_workspace_bytes": (_sz, [_sz]),
+    "dbhip_bitmask_table_reset": (_int, [_vp, _sz, _sz, _vp]),
+    "dbhip_bitmask_table_insert_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, _u32, _int, _vp]),
+    "dbhip_bitmask_table_lookup_u32": (_int, [_vp, _sz, _vp, _sz, _int, _u32, _vp, _vp, _vp]),
     "dbhip_pjoin_partition_workspace_bytes": (_sz, [_sz, _u32]),
     "dbhip_pjoin_partition_u32": (_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dbhip_gather_u32": (_int, [_vp, _vp, _sz, _vp, _vp]),

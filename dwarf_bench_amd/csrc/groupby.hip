@@ -175,28 +175,25 @@ __global__ __launch_bounds__(256) void gb_reduce_kernel(const unsigned *__restri
 
 using namespace dbhip;
 
-extern "C" size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t groups) {
-  (void)n;
-  // sized for the largest device this library targets (256 CUs x 4 workgroups) so the query
-  // needs no device; the launch uses the actual CU count.
-  const GbGeometry g = gb_geometry(groups ? groups : 1, 256);
-  const size_t partial_words = static_cast<size_t>(g.ranges) * g.chunk_slots * g.range_groups;
-  return align_up(kWsHeader + partial_words * sizeof(unsigned), kWsAlign);
+namespace {
+// geometry for a launch: `max_tables` (0 = no limit) caps the number of private tables per key range —
+// the reference's `executors` knob of GroupByLocal (groupby/groupby_local.cpp:27, :58-83)
+GbGeometry gb_launch_geometry(uint32_t groups, uint32_t max_tables, int cus) {
+  GbGeometry geo = gb_geometry(groups, cus < 256 ? cus : 256);
+  if (max_tables && max_tables < geo.chunk_slots) geo.chunk_slots = max_tables;
+  return geo;
 }
 
-extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n,
-                                     uint32_t groups, uint32_t *out, void *workspace,
-                                     size_t workspace_bytes, dbhip_stream_t stream) {
+int gb_partial(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups, uint32_t max_tables,
+               void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (groups == 0) return n == 0 ? DBHIP_OK : DBHIP_EINVAL;
-  if (!out || (n && (!keys || !vals))) return DBHIP_EINVAL;
+  if (n && (!keys || !vals)) return DBHIP_EINVAL;
   if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(vals)) & 15u) return DBHIP_EINVAL;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
-  const int cus = dev.cus < 256 ? dev.cus : 256;
-  const GbGeometry geo = gb_geometry(groups, cus);
+  const GbGeometry geo = gb_launch_geometry(groups, max_tables, dev.cus);
   const size_t partial_words = static_cast<size_t>(geo.ranges) * geo.chunk_slots * geo.range_groups;
-  if (!ws_ok(workspace, workspace_bytes, kWsHeader + partial_words * sizeof(unsigned)))
-    return DBHIP_EWORKSPACE;
+  if (!ws_ok(workspace, workspace_bytes, kWsHeader + partial_words * sizeof(unsigned))) return DBHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
   hipError_t e = hipMemsetAsync(workspace, 0, kWsHeader, s);
   if (e != hipSuccess) return static_cast<int>(e);
@@ -218,7 +215,46 @@ extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals,
     hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads, false>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
                        v4, keys, vals, n, groups, geo, partials, hdr);
   }
-  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, s, partials, geo, groups,
-                     out);
   return launch_status();
+}
+
+int gb_merge(uint32_t groups, uint32_t max_tables, uint32_t *out, const void *workspace, dbhip_stream_t stream) {
+  if (groups == 0) return DBHIP_OK;
+  if (!out || !workspace) return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  const GbGeometry geo = gb_launch_geometry(groups, max_tables, dev.cus);
+  const unsigned *partials = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) + kWsHeader);
+  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, as_stream(stream), partials,
+                     geo, groups, out);
+  return launch_status();
+}
+}  // namespace
+
+extern "C" size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t groups) {
+  (void)n;
+  // sized for the largest device this library targets (256 CUs) so the query needs no device
+  const GbGeometry g = gb_geometry(groups ? groups : 1, 256);
+  const size_t partial_words = static_cast<size_t>(g.ranges) * g.chunk_slots * g.range_groups;
+  return align_up(kWsHeader + partial_words * sizeof(unsigned), kWsAlign);
+}
+
+extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n,
+                                     uint32_t groups, uint32_t *out, void *workspace,
+                                     size_t workspace_bytes, dbhip_stream_t stream) {
+  if (groups && !out) return DBHIP_EINVAL;
+  const int rc = gb_partial(keys, vals, n, groups, 0, workspace, workspace_bytes, stream);
+  return rc != 0 ? rc : gb_merge(groups, 0, out, workspace, stream);
+}
+
+// the two phases separately (GroupByLocal reports them separately, groupby/groupby_local.cpp:115-119)
+extern "C" int dbhip_groupby_partial_u32(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups,
+                                         uint32_t max_private_tables, void *workspace, size_t workspace_bytes,
+                                         dbhip_stream_t stream) {
+  return gb_partial(keys, vals, n, groups, max_private_tables, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dbhip_groupby_merge_u32(uint32_t groups, uint32_t max_private_tables, uint32_t *out,
+                                       const void *workspace, dbhip_stream_t stream) {
+  return gb_merge(groups, max_private_tables, out, workspace, stream);
 }

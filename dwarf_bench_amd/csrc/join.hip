@@ -376,3 +376,170 @@ extern "C" int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t 
                      static_cast<unsigned>(cap - 1), out_key, out_build_val, out_probe_val);
   return launch_status();
 }
+
+// =====================================================================================================
+// Bitmask-claimed open-addressing table: HIP counterpart of SimpleNonOwningHashTable
+// (common/dpcpp/hashtable.hpp:5-93), the table behind the reference's Join and HashBuild dwarfs.
+// Same algorithm: a row claims a free slot by fetch_or on the occupancy word of its hash position,
+// skipping runs of occupied slots with ctz(~(present >> minor)) (hashtable.hpp:70-92); key and payload
+// are then stored plainly (read only by a later launch); lookups walk while the occupancy bit is set
+// (hashtable.hpp:23-62).  Duplicate keys occupy separate slots, as in the reference.  Hashers are the
+// reference's: key % size (StaticSimpleHasher/SimpleHasher, hashfunctions.hpp:33-49) or
+// MurmurHash3_x86_32(key, seed) % size (hashfunctions.hpp:64-137).
+// =====================================================================================================
+namespace dbhip {
+namespace {
+
+struct BmLayout {
+  size_t keys_off, vals_off, mask_off, mask_words, total;
+};
+inline BmLayout bm_layout(size_t size) {
+  BmLayout L;
+  L.keys_off = kWsHeader;
+  L.vals_off = L.keys_off + size * sizeof(unsigned);
+  L.mask_off = align_up(L.vals_off + size * sizeof(unsigned), 16);
+  L.mask_words = (size + 31) / 32;  // join.cpp:31 ceil(ht_size / 32)
+  L.total = align_up(L.mask_off + L.mask_words * sizeof(unsigned), kWsAlign);
+  return L;
+}
+
+__device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ unsigned bm_hash(unsigned key, int kind, unsigned seed, unsigned size) {
+  if (kind == 0) return key % size;
+  unsigned k1 = key * 0xcc9e2d51u;  // one 4-byte block, no tail (hashfunctions.hpp:94-133, _len = 4)
+  k1 = rotl32(k1, 15) * 0x1b873593u;
+  unsigned h1 = seed ^ k1;
+  h1 = rotl32(h1, 13) * 5u + 0xe6546b64u;
+  h1 ^= 4u;
+  return fmix32(h1) % size;
+}
+
+__device__ __forceinline__ void bm_insert(unsigned key, unsigned val, unsigned size, unsigned mask_words,
+                                          int kind, unsigned seed, unsigned *keys, unsigned *vals,
+                                          unsigned *bitmask) {
+  const unsigned at = bm_hash(key, kind, seed, size);
+  unsigned major = at / 32u, minor = at % 32u;
+  unsigned pos;
+  while (true) {  // update_bitmask, hashtable.hpp:70-92
+    const unsigned bit = 1u << minor;
+    const unsigned present = atomicOr(&bitmask[major], bit);
+    if (!(present & bit)) {
+      pos = major * 32u + minor;
+      break;
+    }
+    const unsigned inv = ~(present >> minor);
+    const unsigned occupied = inv ? static_cast<unsigned>(__builtin_ctz(inv)) : 32u;
+    if (occupied + minor >= 32u || major * 32u + minor >= size) {
+      major = (major + 1) % mask_words;
+      minor = 0;
+    } else {
+      minor += occupied;
+    }
+  }
+  keys[pos] = key;  // hashtable.hpp:16-18
+  vals[pos] = val;
+}
+
+__global__ __launch_bounds__(kJoinThreads) void bm_insert_kernel(const unsigned *__restrict__ in_keys,
+                                                                 const unsigned *__restrict__ in_vals, size_t n,
+                                                                 unsigned size, unsigned mask_words, int kind,
+                                                                 unsigned seed, unsigned *keys, unsigned *vals,
+                                                                 unsigned *bitmask, int serial) {
+  if (serial) {  // one work-item inserts in order: reproduces the reference tests' slot layouts
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (size_t i = 0; i < n; ++i) bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask);
+    return;
+  }
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride)
+    bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask);
+}
+
+__global__ __launch_bounds__(kJoinThreads) void bm_lookup_kernel(const unsigned *__restrict__ q, size_t n,
+                                                                 unsigned size, int kind, unsigned seed,
+                                                                 const unsigned *__restrict__ keys,
+                                                                 const unsigned *__restrict__ vals,
+                                                                 const unsigned *__restrict__ bitmask,
+                                                                 unsigned *__restrict__ out_vals,
+                                                                 unsigned *__restrict__ out_found) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned key = q[i];
+    unsigned pos = bm_hash(key, kind, seed, size);
+    const unsigned start = pos;
+    unsigned found = 0, val = 0;
+    bool present = (bitmask[pos / 32u] >> (pos % 32u)) & 1u;
+    while (present) {  // hashtable.hpp:23-40
+      if (keys[pos] == key) {
+        found = 1;
+        val = vals[pos];
+        break;
+      }
+      pos = (pos + 1) % size;
+      if (pos == start) break;
+      present = (bitmask[pos / 32u] >> (pos % 32u)) & 1u;
+    }
+    if (out_vals) out_vals[i] = val;
+    if (out_found) out_found[i] = found;
+  }
+}
+
+}  // namespace
+}  // namespace dbhip
+
+extern "C" size_t dbhip_bitmask_table_workspace_bytes(size_t table_size) {
+  return table_size ? dbhip::bm_layout(table_size).total : 0;
+}
+
+extern "C" int dbhip_bitmask_table_reset(void *workspace, size_t workspace_bytes, size_t table_size,
+                                         dbhip_stream_t stream) {
+  using namespace dbhip;
+  if (table_size == 0 || table_size > 0xFFFFFFFFull) return DBHIP_EINVAL;
+  const BmLayout L = bm_layout(table_size);
+  if (!ws_ok(workspace, workspace_bytes, L.total)) return DBHIP_EWORKSPACE;
+  char *base = static_cast<char *>(workspace);
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = hipMemsetAsync(base + L.keys_off, 0xFF, table_size * sizeof(unsigned), s);  // join.cpp:37
+  if (e == hipSuccess) e = hipMemsetAsync(base + L.vals_off, 0, table_size * sizeof(unsigned), s);
+  if (e == hipSuccess) e = hipMemsetAsync(base + L.mask_off, 0, L.mask_words * sizeof(unsigned), s);
+  return static_cast<int>(e);
+}
+
+extern "C" int dbhip_bitmask_table_insert_u32(const uint32_t *keys, const uint32_t *vals, size_t n, void *workspace,
+                                              size_t workspace_bytes, size_t table_size, int hash_kind,
+                                              uint32_t seed, int serial, dbhip_stream_t stream) {
+  using namespace dbhip;
+  if (n == 0) return DBHIP_OK;
+  if (!keys || !vals || table_size == 0 || table_size > 0xFFFFFFFFull || (hash_kind != 0 && hash_kind != 1))
+    return DBHIP_EINVAL;
+  const BmLayout L = bm_layout(table_size);
+  if (!ws_ok(workspace, workspace_bytes, L.total)) return DBHIP_EWORKSPACE;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  char *base = static_cast<char *>(workspace);
+  hipLaunchKernelGGL(bm_insert_kernel, dim3(serial ? 1 : grid_for(n, dev, 8)), dim3(kJoinThreads), 0, as_stream(stream),
+                     keys, vals, n, static_cast<unsigned>(table_size), static_cast<unsigned>(L.mask_words), hash_kind,
+                     seed, reinterpret_cast<unsigned *>(base + L.keys_off), reinterpret_cast<unsigned *>(base + L.vals_off),
+                     reinterpret_cast<unsigned *>(base + L.mask_off), serial);
+  return launch_status();
+}
+
+extern "C" int dbhip_bitmask_table_lookup_u32(const uint32_t *keys, size_t n, const void *workspace, size_t table_size,
+                                              int hash_kind, uint32_t seed, uint32_t *out_vals, uint32_t *out_found,
+                                              dbhip_stream_t stream) {
+  using namespace dbhip;
+  if (n == 0) return DBHIP_OK;
+  if (!keys || !workspace || table_size == 0 || table_size > 0xFFFFFFFFull || (hash_kind != 0 && hash_kind != 1))
+    return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  const BmLayout L = bm_layout(table_size);
+  const char *base = static_cast<const char *>(workspace);
+  hipLaunchKernelGGL(bm_lookup_kernel, dim3(grid_for(n, dev, 8)), dim3(kJoinThreads), 0, as_stream(stream), keys, n,
+                     static_cast<unsigned>(table_size), hash_kind, seed,
+                     reinterpret_cast<const unsigned *>(base + L.keys_off),
+                     reinterpret_cast<const unsigned *>(base + L.vals_off),
+                     reinterpret_cast<const unsigned *>(base + L.mask_off), out_vals, out_found);
+  return launch_status();
+}

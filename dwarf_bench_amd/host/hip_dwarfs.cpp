@@ -122,7 +122,7 @@ void run_scan(const char *who, size_t n, Meter &meter) {
   if (validate) {  // scan/scan.cpp:12-17 expected_out_lt
     const std::vector<int32_t> host = src.to_host(n);
     std::copy_if(host.begin(), host.end(), std::back_inserter(expected),
-                 [filter_value](int v) { return v < filter_value; });
+                 [](int v) { return v < filter_value; });
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -387,3 +387,140 @@ void JoinHip::run(const RunOptions &opts) {
   for (auto size : opts.input_size) _run(size, meter());
 }
 void JoinHip::init(const RunOptions &opts) { common_init(*this, opts); }
+
+// =====================================================================================================
+// GroupByLocalHip — the reference's privatised group-by as its own dwarf (groupby/groupby_local.cpp:24-142):
+// GroupByAggResult with the two phases timed separately and the CSV header
+// "total_time,group_by_time,reduction_time"; --executors caps the number of private tables.
+GroupByLocalHip::GroupByLocalHip() : Dwarf("GroupByLocalHip") {}
+void GroupByLocalHip::_run(const size_t n, Meter &meter) {
+  const auto &opts = static_cast<const GroupByRunOptions &>(meter.opts());
+  banner("GroupByLocalHip");
+  const uint32_t groups = static_cast<uint32_t>(opts.groups_count ? opts.groups_count : 1);
+  const uint32_t executors = static_cast<uint32_t>(opts.executors);
+  DevBuf<uint32_t> keys(n), vals(n), out(groups);
+  const size_t ws_bytes = dbhip_groupby_sum_u32_workspace_bytes(n, groups);
+  DevBuf<unsigned char> ws(ws_bytes);
+  db_ok(dbhip_gen_uniform_u32(vals.get(), n, 43, 0, 1, 10000, nullptr), "gen vals");
+  db_ok(dbhip_gen_uniform_u32(keys.get(), n, 42, 0, 0, groups - 1, nullptr), "gen keys");
+  hip_ok(hipDeviceSynchronize(), "sync");
+  const bool validate = n <= validate_limit();
+  std::vector<uint32_t> expected(groups, 0);
+  if (validate) {
+    const auto hk = keys.to_host(n);
+    const auto hv = vals.to_host(n);
+    for (size_t i = 0; i < n; ++i) expected[hk[i]] = expected[hk[i]] + hv[i];
+  }
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    auto result = std::make_unique<GroupByAggResult>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    db_ok(dbhip_groupby_partial_u32(keys.get(), vals.get(), n, groups, executors, ws.get(), ws_bytes, nullptr),
+          "dbhip_groupby_partial_u32");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");  // the reference waits between the two kernels (:83, :112)
+    const auto group_by_end = clk::now();
+    db_ok(dbhip_groupby_merge_u32(groups, executors, out.get(), ws.get(), nullptr), "dbhip_groupby_merge_u32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->group_by_time = group_by_end - host_start;
+    result->reduction_time = host_end - group_by_end;
+    result->kernel_time = ev.elapsed();
+    check_status(ws.get(), "GroupByLocalHip");
+    if (validate && out.to_host(groups) != expected) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void GroupByLocalHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void GroupByLocalHip::init(const RunOptions &opts) {
+  reporting_header_ = "total_time,group_by_time,reduction_time";  // groupby_local.cpp:138
+  common_init(*this, opts);
+}
+
+// =====================================================================================================
+// HashBuildHip — build-only timing of the bitmask-claimed table (hash/hash_build.cpp:8-98): every row
+// inserts (key, key) into a table of 2n slots, Murmur3 hash; afterwards every key must be found.
+HashBuildHip::HashBuildHip() : Dwarf("HashBuildHip") {}
+void HashBuildHip::_run(const size_t n, Meter &meter) {
+  const RunOptions &opts = meter.opts();
+  banner("HashBuildHip");
+  const size_t ht_size = n ? n * 2 : 1;  // hash_build.cpp:19
+  const uint32_t seed = 421;             // the reference draws it at random (helpers::make_random)
+  DevBuf<uint32_t> src(n), found(n);
+  const size_t ws_bytes = dbhip_bitmask_table_workspace_bytes(ht_size);
+  DevBuf<unsigned char> ws(ws_bytes);
+  db_ok(dbhip_gen_uniform_u32(src.get(), n, 42, 0, 1, 10000, nullptr), "gen");
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    db_ok(dbhip_bitmask_table_reset(ws.get(), ws_bytes, ht_size, nullptr), "reset");  // fresh table, untimed (:23-26)
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    auto result = std::make_unique<Result>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    db_ok(dbhip_bitmask_table_insert_u32(src.get(), src.get(), n, ws.get(), ws_bytes, ht_size, 1, seed, 0, nullptr),
+          "dbhip_bitmask_table_insert_u32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->kernel_time = ev.elapsed();
+    // hash_build.cpp:60-83: has(key) must be 1 for every inserted key
+    db_ok(dbhip_bitmask_table_lookup_u32(src.get(), n, ws.get(), ht_size, 1, seed, nullptr, found.get(), nullptr),
+          "dbhip_bitmask_table_lookup_u32");
+    const auto h = found.to_host(n);
+    if (!std::all_of(h.begin(), h.end(), [](uint32_t f) { return f == 1u; })) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void HashBuildHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void HashBuildHip::init(const RunOptions &opts) { common_init(*this, opts); }
+
+// =====================================================================================================
+// HashBuildNonBitmaskHip — build-only timing of the CAS-claimed table (hash/hash_build_non_bitmask.cpp:7-91):
+// distinct keys claim slots with atomicCAS, duplicates land on the same slot; every key must be found.
+HashBuildNonBitmaskHip::HashBuildNonBitmaskHip() : Dwarf("HashBuildNonBitmaskHip") {}
+void HashBuildNonBitmaskHip::_run(const size_t n, Meter &meter) {
+  const RunOptions &opts = meter.opts();
+  banner("HashBuildNonBitmaskHip");
+  DevBuf<uint32_t> src(n), ok_(n), o1(n), o2(n);
+  const size_t ws_bytes = dbhip_ujoin_workspace_bytes(n);
+  DevBuf<unsigned char> ws(ws_bytes);
+  db_ok(dbhip_gen_uniform_u32(src.get(), n, 42, 0, 1, 10000, nullptr), "gen");
+  hip_ok(hipDeviceSynchronize(), "sync");
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    auto result = std::make_unique<Result>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    db_ok(dbhip_ujoin_build_u32(src.get(), src.get(), n, ws.get(), ws_bytes, nullptr), "dbhip_ujoin_build_u32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->kernel_time = ev.elapsed();
+    check_status(ws.get(), "HashBuildNonBitmaskHip");
+    db_ok(dbhip_ujoin_probe_u32(src.get(), src.get(), n, ws.get(), n, ok_.get(), o1.get(), o2.get(), nullptr), "probe");
+    const auto hk = ok_.to_host(n), hs = src.to_host(n);
+    if (hk != hs) {  // every key found (a miss would leave the 0xFFFFFFFF sentinel)
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void HashBuildNonBitmaskHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void HashBuildNonBitmaskHip::init(const RunOptions &opts) { common_init(*this, opts); }

@@ -6,6 +6,7 @@
 //   GroupByHip                    groupby/groupby.cpp:24-122
 //   JoinOmnisciHip                join/join_omnisci.cpp:49-118
 //   JoinHip                       join/join.cpp:8-154
+//   GroupByLocalHip, HashBuildHip, HashBuildNonBitmaskHip: the "next" rows of SURVEY 8(f)
 #pragma once
 #include "dwarf_api.hpp"
 
@@ -26,5 +27,9 @@ DBHIP_DECLARE_DWARF(RadixHip);
 DBHIP_DECLARE_DWARF(GroupByHip);
 DBHIP_DECLARE_DWARF(JoinOmnisciHip);
 DBHIP_DECLARE_DWARF(JoinHip);
+// SURVEY 8(f) "next" rows
+DBHIP_DECLARE_DWARF(GroupByLocalHip);         // groupby/groupby_local.cpp:24-142 (two-phase timings, --executors)
+DBHIP_DECLARE_DWARF(HashBuildHip);            // hash/hash_build.cpp:8-98 (bitmask-claimed table, build only)
+DBHIP_DECLARE_DWARF(HashBuildNonBitmaskHip);  // hash/hash_build_non_bitmask.cpp:7-91 (CAS table, build only)
 
 #undef DBHIP_DECLARE_DWARF

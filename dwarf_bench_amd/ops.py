@@ -148,6 +148,21 @@ class GroupBySum:
                                                       self.out.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
                                                       _stream()), "groupby_sum_u32")
 
+    def partial(self, keys: torch.Tensor, vals: torch.Tensor, max_private_tables: int = 0) -> None:
+        """phase 1 of groupby/groupby_local.cpp:52-83: privatised partial sums; 0 = let the library choose"""
+        _need(keys, torch.int32, "keys")
+        _need(vals, torch.int32, "vals")
+        if keys.numel() != self.n or vals.numel() != self.n:
+            raise ValueError("size mismatch")
+        _capi.check(_capi.lib().dbhip_groupby_partial_u32(keys.data_ptr(), vals.data_ptr(), self.n, self.groups,
+                                                          max_private_tables, self.ws.data_ptr(), self.ws_bytes,
+                                                          _stream()), "groupby_partial_u32")
+
+    def merge(self, max_private_tables: int = 0) -> None:
+        """phase 2 (groupby_local.cpp:85-112): fold the private tables into the result"""
+        _capi.check(_capi.lib().dbhip_groupby_merge_u32(self.groups, max_private_tables, self.out.data_ptr(),
+                                                        self.ws.data_ptr(), _stream()), "groupby_merge_u32")
+
     def result(self) -> torch.Tensor:
         _check_status(self.ws, "groupby_sum_u32")
         return self.out[: self.groups]
@@ -257,3 +272,40 @@ def gather_u32(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _capi.check(_capi.lib().dbhip_gather_u32(table.data_ptr(), idx.data_ptr(), idx.numel(), out.data_ptr(), _stream()),
                 "gather_u32")
     return out[: idx.numel()]
+
+
+# ---------------------------------------------------------------------------------------------
+# bitmask-claimed table (SimpleNonOwningHashTable counterpart)
+# ---------------------------------------------------------------------------------------------
+class BitmaskTable:
+    def __init__(self, table_size: int, hash_kind: int = 1, seed: int = 0, device="cuda"):
+        self.size, self.kind, self.seed = table_size, hash_kind, seed
+        self.ws_bytes = _capi.lib().dbhip_bitmask_table_workspace_bytes(table_size)
+        self.ws = _ws(self.ws_bytes, device)
+        self.reset()
+
+    def reset(self) -> None:
+        _capi.check(_capi.lib().dbhip_bitmask_table_reset(self.ws.data_ptr(), self.ws_bytes, self.size, _stream()),
+                    "bitmask_table_reset")
+
+    def insert(self, keys: torch.Tensor, vals: torch.Tensor, serial: bool = False) -> None:
+        _need(keys, torch.int32, "keys")
+        _need(vals, torch.int32, "vals")
+        _capi.check(_capi.lib().dbhip_bitmask_table_insert_u32(keys.data_ptr(), vals.data_ptr(), keys.numel(),
+                                                               self.ws.data_ptr(), self.ws_bytes, self.size, self.kind,
+                                                               self.seed, int(serial), _stream()), "bitmask_table_insert")
+
+    def lookup(self, keys: torch.Tensor):
+        _need(keys, torch.int32, "keys")
+        n = keys.numel()
+        vals = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
+        found = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
+        _capi.check(_capi.lib().dbhip_bitmask_table_lookup_u32(keys.data_ptr(), n, self.ws.data_ptr(), self.size,
+                                                               self.kind, self.seed, vals.data_ptr(), found.data_ptr(),
+                                                               _stream()), "bitmask_table_lookup")
+        return vals[:n], found[:n]
+
+    def slot_values(self) -> torch.Tensor:
+        """the payload array of the table (for slot-level known-answer tests)"""
+        off = 256 + 4 * self.size
+        return self.ws[off: off + 4 * self.size].view(torch.int32)

@@ -100,6 +100,16 @@ int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n, 
                           uint32_t *out, void *workspace, size_t workspace_bytes,
                           dbhip_stream_t stream);
 
+/* The two phases on their own (GroupByLocal reports group_by_time and reduction_time separately,
+ * groupby/groupby_local.cpp:115-119): partial = private per-workgroup LDS tables written to the workspace,
+ * merge = their sum into out[].  max_private_tables caps the number of private tables per key range
+ * (the reference's `executors`); 0 = one per compute unit.  Same workspace size as the fused call.      */
+int dbhip_groupby_partial_u32(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups,
+                              uint32_t max_private_tables, void *workspace, size_t workspace_bytes,
+                              dbhip_stream_t stream);
+int dbhip_groupby_merge_u32(uint32_t groups, uint32_t max_private_tables, uint32_t *out, const void *workspace,
+                            dbhip_stream_t stream);
+
 /* ---- dwarf 4a: one-to-many hash join (JoinOmnisci semantics) -----------------------------------
  * Build: hash table over the DISTINCT build keys, per-key match count, exclusive scan -> position,
  * ids[pos .. pos+count) = build row indices carrying that key (order inside a key's range is not
@@ -130,6 +140,21 @@ int dbhip_ujoin_build_u32(const uint32_t *build_keys, const uint32_t *build_vals
 int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t *probe_vals, size_t n_probe,
                           const void *workspace, size_t n_build, uint32_t *out_key,
                           uint32_t *out_build_val, uint32_t *out_probe_val, dbhip_stream_t stream);
+
+/* ---- bitmask-claimed table: HIP counterpart of SimpleNonOwningHashTable (common/dpcpp/hashtable.hpp:5-93),
+ * the table of the reference's Join / HashBuild dwarfs: slots claimed by fetch_or on an occupancy bitmask
+ * + ctz over occupied runs; duplicate keys take separate slots.  hash_kind 0 = key % table_size
+ * (StaticSimpleHasher / SimpleHasher), 1 = MurmurHash3_x86_32(key, seed) % table_size
+ * (hashfunctions.hpp:64-137).  serial != 0 inserts with ONE work-item in input order (reproduces the slot
+ * layouts the reference's hash_table_tests expect).  Workspace: header | keys[size] | vals[size] | bitmask. */
+size_t dbhip_bitmask_table_workspace_bytes(size_t table_size);
+int dbhip_bitmask_table_reset(void *workspace, size_t workspace_bytes, size_t table_size, dbhip_stream_t stream);
+int dbhip_bitmask_table_insert_u32(const uint32_t *keys, const uint32_t *vals, size_t n, void *workspace,
+                                   size_t workspace_bytes, size_t table_size, int hash_kind, uint32_t seed,
+                                   int serial, dbhip_stream_t stream);
+int dbhip_bitmask_table_lookup_u32(const uint32_t *keys, size_t n, const void *workspace, size_t table_size,
+                                   int hash_kind, uint32_t seed, uint32_t *out_vals, uint32_t *out_found,
+                                   dbhip_stream_t stream);
 
 /* ---- multi-GPU radix-partitioned join: device pieces (no reference counterpart) ---------
  * Partition a local column shard into `parts` (1..256) destination buckets by the mixed hash of

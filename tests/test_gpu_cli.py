@@ -16,7 +16,8 @@ def _run(args, **kw):
     return subprocess.run([str(LIB / "dwarf_bench")] + args, capture_output=True, text=True, timeout=300, **kw)
 
 
-@pytest.mark.parametrize("dwarf", ["TwoPassScanHip", "DPLScanHip", "RadixHip", "JoinOmnisciHip", "JoinHip"])
+@pytest.mark.parametrize("dwarf", ["TwoPassScanHip", "DPLScanHip", "RadixHip", "JoinOmnisciHip", "JoinHip",
+                                   "HashBuildHip", "HashBuildNonBitmaskHip"])
 def test_dwarf_suite(dwarf):
     r = _run([dwarf, "--device=hip", "--iterations", "10", "--input_size"] + SIZES)
     assert r.returncode == 0, r.stderr
@@ -32,6 +33,21 @@ def test_groupby_suite_with_reference_test_options():
               "--input_size"] + SIZES)
     assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
     assert r.stdout.count("Host duration:") == 10 * len(SIZES)
+
+
+@pytest.mark.parametrize("executors", ["1", "16", "1024"])
+def test_groupby_local_suite(tmp_path, executors):
+    """GroupByLocal (groupby/groupby_local.cpp:24-142): two-phase timings and its own CSV header (:138)"""
+    rep = tmp_path / "gbl.csv"
+    r = _run(["GroupByLocalHip", "--device=hip", "--iterations", "10", "--groups_count", "64", "--executors", executors,
+              f"--report_path={rep}", "--input_size"] + SIZES + ["1048576"])
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    rows = list(csv.reader(rep.open()))
+    assert rows[0] == ["device_type", "buf_size_bytes", "total_time", "group_by_time", "reduction_time"]
+    assert len(rows) == 1 + 10 * (len(SIZES) + 1)
+    for row in rows[1:]:
+        total, gb, red = (float(x) for x in row[2:5])
+        assert row[0] == "HIP" and gb > 0 and red >= 0 and abs(total - (gb + red)) <= 0.0025  # whole-us truncation
 
 
 def test_baseline_plumbing_config_csv(tmp_path):

@@ -71,3 +71,37 @@ def test_baseline_config_2_26_rows_2_16_groups():
     kh, vh = keys[:m].cpu().numpy().view(np.uint32), vals[:m].cpu().numpy().view(np.uint32)
     assert np.array_equal(ops.groupby_sum(keys[:m], vals[:m], groups).cpu().numpy().view(np.uint32),
                           po.groupby_sum(kh, vh, groups))
+
+
+# ---- two-phase entry points (GroupByLocal, groupby/groupby_local.cpp:52-112) --------------------------
+@pytest.mark.parametrize("executors", [0, 1, 2, 7, 64, 1024, 1 << 20])
+@pytest.mark.parametrize("n,groups", [(0, 3), (5, 1), (4096, 64), (100003, 257), (1 << 20, 64), (1 << 20, 40000),
+                                      (300000, 100000)])
+def test_partial_then_merge(n, groups, executors):
+    from dwarf_bench_amd import ops
+    keys = po.gen_uniform_u32(n, 42, 0, groups - 1)
+    vals = po.gen_uniform_u32(n, 43, 1, 10000)
+    k = torch.from_numpy(keys.view(np.int32)).cuda()
+    v = torch.from_numpy(vals.view(np.int32)).cuda()
+    plan = ops.GroupBySum(n, groups)
+    plan.partial(k, v, executors)
+    plan.merge(executors)
+    got = plan.result().cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, po.groupby_sum(keys, vals, groups))
+    if n and executors:  # the oracle's own privatised form agrees too (threads_count = executors)
+        assert np.array_equal(got, po.groupby_local(keys, vals, groups, min(executors, 1024)))
+
+
+def test_partial_merge_is_repeatable():
+    from dwarf_bench_amd import ops
+    n, groups = 200000, 64
+    keys = po.gen_uniform_u32(n, 5, 0, groups - 1)
+    vals = po.gen_uniform_u32(n, 6, 1, 10000)
+    k = torch.from_numpy(keys.view(np.int32)).cuda()
+    v = torch.from_numpy(vals.view(np.int32)).cuda()
+    plan = ops.GroupBySum(n, groups)
+    want = po.groupby_sum(keys, vals, groups)
+    for executors in (4, 0, 4):
+        plan.partial(k, v, executors)
+        plan.merge(executors)
+        assert np.array_equal(plan.result().cpu().numpy().view(np.uint32), want)

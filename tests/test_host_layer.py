@@ -68,7 +68,8 @@ def test_cli_list_and_exit_codes():
     r = subprocess.run([str(exe), "list"], capture_output=True, text=True)
     assert r.returncode == 0
     names = [l.strip() for l in r.stdout.splitlines() if l.startswith("\t")]
-    assert names == sorted(["DPLScanHip", "GroupByHip", "JoinHip", "JoinOmnisciHip", "RadixHip", "TwoPassScanHip"])
+    assert names == sorted(["DPLScanHip", "GroupByHip", "GroupByLocalHip", "HashBuildHip", "HashBuildNonBitmaskHip", "JoinHip",
+                            "JoinOmnisciHip", "RadixHip", "TwoPassScanHip"])
     assert "DWARF_BENCH_ROOT is set to" in r.stdout
     r = subprocess.run([str(exe), "NoSuchDwarf"], capture_output=True, text=True)
     assert r.returncode == 1 and "List supported dwarfs" in r.stderr  # main.cpp:75-79
