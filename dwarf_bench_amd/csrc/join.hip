@@ -414,13 +414,30 @@ __device__ __forceinline__ unsigned bm_hash(unsigned key, int kind, unsigned see
   return fmix32(h1) % size;
 }
 
+// One departure from hashtable.hpp:70-92, not visible where the reference is well defined: `minor += occupied`
+// may step onto a slot >= size in a ragged last word, which the reference would then claim and write out of
+// bounds; here that step wraps to word 0 like any other end of table.  A table with no free slot makes the
+// reference spin forever; here the walk gives up after two laps' worth of visits and raises DBHIP_DEV_TABLE_FULL.
+// (Measured and rejected: peeking the word with a plain or sc1 load before the fetch_or to skip full words
+// without an atomic — 1.5-4x slower at every size, for unique and for duplicate-heavy keys alike.)
 __device__ __forceinline__ void bm_insert(unsigned key, unsigned val, unsigned size, unsigned mask_words,
                                           int kind, unsigned seed, unsigned *keys, unsigned *vals,
-                                          unsigned *bitmask) {
+                                          unsigned *bitmask, unsigned *status) {
   const unsigned at = bm_hash(key, kind, seed, size);
   unsigned major = at / 32u, minor = at % 32u;
   unsigned pos;
+  unsigned long long budget = 64ull * mask_words + 64;  // visits: at most 32 per word per lap
   while (true) {  // update_bitmask, hashtable.hpp:70-92
+    if (budget == 0) {
+      atomicOr(status, static_cast<unsigned>(DBHIP_DEV_TABLE_FULL));
+      return;
+    }
+    --budget;
+    if (major * 32u + minor >= size) {  // ragged last word: nothing claimable from here on
+      major = 0;
+      minor = 0;
+      continue;
+    }
     const unsigned bit = 1u << minor;
     const unsigned present = atomicOr(&bitmask[major], bit);
     if (!(present & bit)) {
@@ -429,7 +446,7 @@ __device__ __forceinline__ void bm_insert(unsigned key, unsigned val, unsigned s
     }
     const unsigned inv = ~(present >> minor);
     const unsigned occupied = inv ? static_cast<unsigned>(__builtin_ctz(inv)) : 32u;
-    if (occupied + minor >= 32u || major * 32u + minor >= size) {
+    if (occupied + minor >= 32u) {
       major = (major + 1) % mask_words;
       minor = 0;
     } else {
@@ -444,15 +461,16 @@ __global__ __launch_bounds__(kJoinThreads) void bm_insert_kernel(const unsigned 
                                                                  const unsigned *__restrict__ in_vals, size_t n,
                                                                  unsigned size, unsigned mask_words, int kind,
                                                                  unsigned seed, unsigned *keys, unsigned *vals,
-                                                                 unsigned *bitmask, int serial) {
+                                                                 unsigned *bitmask, unsigned *status,
+                                                                 int serial) {
   if (serial) {  // one work-item inserts in order: reproduces the reference tests' slot layouts
     if (blockIdx.x == 0 && threadIdx.x == 0)
-      for (size_t i = 0; i < n; ++i) bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask);
+      for (size_t i = 0; i < n; ++i) bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask, status);
     return;
   }
   const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride)
-    bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask);
+    bm_insert(in_keys[i], in_vals[i], size, mask_words, kind, seed, keys, vals, bitmask, status);
 }
 
 __global__ __launch_bounds__(kJoinThreads) void bm_lookup_kernel(const unsigned *__restrict__ q, size_t n,
@@ -521,7 +539,7 @@ extern "C" int dbhip_bitmask_table_insert_u32(const uint32_t *keys, const uint32
   hipLaunchKernelGGL(bm_insert_kernel, dim3(serial ? 1 : grid_for(n, dev, 8)), dim3(kJoinThreads), 0, as_stream(stream),
                      keys, vals, n, static_cast<unsigned>(table_size), static_cast<unsigned>(L.mask_words), hash_kind,
                      seed, reinterpret_cast<unsigned *>(base + L.keys_off), reinterpret_cast<unsigned *>(base + L.vals_off),
-                     reinterpret_cast<unsigned *>(base + L.mask_off), serial);
+                     reinterpret_cast<unsigned *>(base + L.mask_off), reinterpret_cast<unsigned *>(base), serial);
   return launch_status();
 }
 

@@ -1,0 +1,113 @@
+// reduce_nlj.hip — the two small dwarfs that complete the reference's taxonomy:
+//
+//   * sum-reduce of an int32 column (reduce/reduce.cpp:27-88: oneAPI reduction with plus<>, result an
+//     int; here int32 wrap-around addition, which is associative, so any summation order is bit-exact);
+//   * nested-loop equi-join (join/nested_join.cpp:10-100): the dense |A| x |B| cell matrix the reference
+//     fills, cell (i, j) = (key, a_val[i], b_val[j]) when a_key[i] == b_key[j].  Unlike the reference,
+//     which pre-fills the matrix on the host (key 0, values 0xFFFFFFFF, :30-32) and re-uploads it every
+//     iteration, the kernel writes every cell itself, matches and misses alike, so no pre-fill pass exists
+//     and the stores are full coalesced rows.  A small-n device oracle for the hash joins.
+//
+// Both are HBM-bound: reduce reads 4 B/row once (nontemporal 16-B loads, 8 in flight per lane),
+// nested-loop join writes 12 B per cell.
+#include "dbhip_common.hpp"
+
+namespace dbhip {
+namespace {
+
+constexpr int kRedThreads = 512;
+constexpr int kRedVecsPerLane = 8;  // 8 x 16 B in flight per lane
+constexpr size_t kRedTileInts = static_cast<size_t>(kRedThreads) * kRedVecsPerLane * 4;  // 64 KiB tiles
+
+__global__ __launch_bounds__(kRedThreads) void reduce_sum_kernel(const int *__restrict__ src, size_t n,
+                                                                 unsigned *__restrict__ out) {
+  __shared__ unsigned wave_sums[kRedThreads / kWave];
+  unsigned acc = 0;
+  const size_t full_tiles = n / kRedTileInts;
+  const i32x4 *vsrc = reinterpret_cast<const i32x4 *>(src);
+  for (size_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
+    const i32x4 *p = vsrc + t * (kRedTileInts / 4) + threadIdx.x;
+    i32x4 v[kRedVecsPerLane];
+#pragma unroll
+    for (int k = 0; k < kRedVecsPerLane; ++k) v[k] = __builtin_nontemporal_load(p + k * kRedThreads);
+#pragma unroll
+    for (int k = 0; k < kRedVecsPerLane; ++k)
+      acc += static_cast<unsigned>(v[k].x) + static_cast<unsigned>(v[k].y) + static_cast<unsigned>(v[k].z) +
+             static_cast<unsigned>(v[k].w);
+  }
+  // ragged tail (< one tile), shared by the grid
+  const size_t tail0 = full_tiles * kRedTileInts;
+  for (size_t i = tail0 + static_cast<size_t>(blockIdx.x) * kRedThreads + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * kRedThreads)
+    acc += static_cast<unsigned>(src[i]);
+
+  acc = wave_reduce_add(acc);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == kWave - 1) wave_sums[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned s = 0;
+#pragma unroll
+    for (int w = 0; w < kRedThreads / kWave; ++w) s += wave_sums[w];
+    if (s) atomicAdd(out, s);
+  }
+}
+
+// one workgroup = 256 B columns x kNljRows A rows; B keys/values live in registers, A rows are wave-uniform
+constexpr int kNljThreads = 256;
+constexpr int kNljRows = 16;
+constexpr unsigned kNljMiss = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kNljThreads) void nested_join_kernel(
+    const unsigned *__restrict__ a_keys, const unsigned *__restrict__ a_vals,
+    const unsigned *__restrict__ b_keys, const unsigned *__restrict__ b_vals, size_t n_a, size_t n_b,
+    unsigned *__restrict__ out_key, unsigned *__restrict__ out_val1, unsigned *__restrict__ out_val2) {
+  const size_t j = static_cast<size_t>(blockIdx.x) * kNljThreads + threadIdx.x;
+  const size_t i0 = static_cast<size_t>(blockIdx.y) * kNljRows;
+  if (j >= n_b) return;
+  const unsigned bk = b_keys[j], bv = b_vals[j];
+  const size_t i1 = i0 + kNljRows < n_a ? i0 + kNljRows : n_a;
+  for (size_t i = i0; i < i1; ++i) {
+    const unsigned ak = a_keys[i], av = a_vals[i];  // uniform across the workgroup: scalar loads
+    const bool hit = ak == bk;
+    const size_t cell = i * n_b + j;
+    out_key[cell] = hit ? ak : 0u;  // the reference's "no row here" markers (nested_join.cpp:30-32, :85)
+    out_val1[cell] = hit ? av : kNljMiss;
+    out_val2[cell] = hit ? bv : kNljMiss;
+  }
+}
+
+}  // namespace
+}  // namespace dbhip
+
+using namespace dbhip;
+
+extern "C" int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, dbhip_stream_t stream) {
+  if (!out || (n && !src)) return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (n == 0) return DBHIP_OK;
+  const size_t tiles = (n + kRedTileInts - 1) / kRedTileInts;
+  const size_t cap = static_cast<size_t>(dev.cus) * 4;  // 4 x 512 threads per CU: full occupancy
+  const unsigned grid = static_cast<unsigned>(tiles < cap ? tiles : cap);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid), dim3(kRedThreads), 0, s, src, n,
+                     reinterpret_cast<unsigned *>(out));
+  return launch_status();
+}
+
+extern "C" int dbhip_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, const uint32_t *b_keys,
+                                     const uint32_t *b_vals, size_t n_a, size_t n_b, uint32_t *out_key,
+                                     uint32_t *out_val1, uint32_t *out_val2, dbhip_stream_t stream) {
+  if (n_a == 0 || n_b == 0) return DBHIP_OK;
+  if (!a_keys || !a_vals || !b_keys || !b_vals || !out_key || !out_val1 || !out_val2) return DBHIP_EINVAL;
+  const size_t row_groups = (n_a + kNljRows - 1) / kNljRows;
+  const size_t col_groups = (n_b + kNljThreads - 1) / kNljThreads;
+  if (row_groups > 65535 || col_groups > 0x7FFFFFFFull) return DBHIP_EINVAL;  // n_a <= 1,048,560 rows
+  hipLaunchKernelGGL(nested_join_kernel, dim3(static_cast<unsigned>(col_groups), static_cast<unsigned>(row_groups)),
+                     dim3(kNljThreads), 0, as_stream(stream), a_keys, a_vals, b_keys, b_vals, n_a, n_b, out_key,
+                     out_val1, out_val2);
+  return launch_status();
+}

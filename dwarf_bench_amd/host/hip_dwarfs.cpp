@@ -17,8 +17,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <unordered_map>
 
@@ -47,9 +49,33 @@ class DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
   T *get() const { return static_cast<T *>(p_); }
   size_t size() const { return n_; }
+  // Validation copies go through one pinned staging buffer: a hipMemcpy into pageable memory pins and
+  // lazily unpins the destination, and that unpin lands inside the NEXT iteration's timed launch
+  // (measured: 40 us -> 7-13 ms of host_time after a 64 MiB pageable D2H).
   std::vector<T> to_host(size_t count) const {
     std::vector<T> h(count);
-    if (count) hip_ok(hipMemcpy(h.data(), p_, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    const size_t bytes = count * sizeof(T);
+    if (bytes == 0) return h;
+    if (bytes < (static_cast<size_t>(1) << 20)) {
+      hip_ok(hipMemcpy(h.data(), p_, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+      return h;
+    }
+    struct Pinned {
+      void *p = nullptr;
+      size_t cap = 0;
+      ~Pinned() { (void)hipHostFree(p); }
+    };
+    static Pinned stage;
+    constexpr size_t kChunk = static_cast<size_t>(64) << 20;
+    if (!stage.p) {
+      hip_ok(hipHostMalloc(&stage.p, kChunk, hipHostMallocDefault), "hipHostMalloc");
+      stage.cap = kChunk;
+    }
+    for (size_t off = 0; off < bytes; off += stage.cap) {
+      const size_t len = std::min(stage.cap, bytes - off);
+      hip_ok(hipMemcpy(stage.p, static_cast<const char *>(p_) + off, len, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+      std::memcpy(reinterpret_cast<char *>(h.data()) + off, stage.p, len);
+    }
     return h;
   }
 
@@ -471,6 +497,7 @@ void HashBuildHip::_run(const size_t n, Meter &meter) {
     const auto host_end = clk::now();
     result->host_time = host_end - host_start;
     result->kernel_time = ev.elapsed();
+    check_status(ws.get(), "HashBuildHip");
     // hash_build.cpp:60-83: has(key) must be 1 for every inserted key
     db_ok(dbhip_bitmask_table_lookup_u32(src.get(), n, ws.get(), ht_size, 1, seed, nullptr, found.get(), nullptr),
           "dbhip_bitmask_table_lookup_u32");
@@ -524,3 +551,100 @@ void HashBuildNonBitmaskHip::run(const RunOptions &opts) {
   for (auto size : opts.input_size) _run(size, meter());
 }
 void HashBuildNonBitmaskHip::init(const RunOptions &opts) { common_init(*this, opts); }
+
+// =====================================================================================================
+// ReduceHip — int sum of a column (reduce/reduce.cpp:27-98); expected = std::accumulate(..., 0) (:21).
+ReduceHip::ReduceHip() : Dwarf("ReduceHip") {}
+void ReduceHip::_run(const size_t n, Meter &meter) {
+  const RunOptions &opts = meter.opts();
+  banner("ReduceHip");
+  DevBuf<int32_t> src(n), out(1);
+  db_ok(dbhip_gen_uniform_u32(reinterpret_cast<uint32_t *>(src.get()), n, 42, 0, 1, 10000, nullptr), "gen");
+  hip_ok(hipDeviceSynchronize(), "sync");
+  const bool validate = n <= validate_limit();
+  int32_t expected = 0;
+  if (validate) {
+    const auto h = src.to_host(n);
+    uint32_t acc = 0;  // accumulate with defined wrap-around; equals the int sum wherever that is defined
+    for (int32_t v : h) acc += static_cast<uint32_t>(v);
+    expected = static_cast<int32_t>(acc);
+  }
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    auto result = std::make_unique<Result>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    db_ok(dbhip_reduce_sum_i32(src.get(), n, out.get(), nullptr), "dbhip_reduce_sum_i32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    int32_t host_out = 0;
+    hip_ok(hipMemcpy(&host_out, out.get(), sizeof(host_out), hipMemcpyDeviceToHost), "D2H");  // syncs
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->kernel_time = ev.elapsed();
+    result->bytes = n * sizeof(int32_t);
+    if (validate && host_out != expected) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void ReduceHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void ReduceHip::init(const RunOptions &opts) { common_init(*this, opts); }
+
+// =====================================================================================================
+// NestedLoopJoinHip — join/nested_join.cpp:10-110: n x n cell matrix on the device, compacted on the host in
+// cell order (:81-90), compared with the a-major/b-minor nested loop of join_helpers::seq_join.
+NestedLoopJoinHip::NestedLoopJoinHip() : Dwarf("NestedLoopJoinHip") {}
+void NestedLoopJoinHip::_run(const size_t n, Meter &meter) {
+  const RunOptions &opts = meter.opts();
+  banner("NestedLoopJoinHip");
+  if (n > (static_cast<size_t>(1) << 15)) fail("NestedLoopJoinHip: the n x n cell matrix is limited to n <= 32768");
+  const size_t cells = n * n;
+  DevBuf<uint32_t> ak(n), av(n), bk(n), bv(n), ok_(cells), o1(cells), o2(cells);
+  db_ok(dbhip_gen_uniform_u32(ak.get(), n, 42, 0, 1, 10000, nullptr), "gen");
+  db_ok(dbhip_gen_uniform_u32(av.get(), n, 43, 0, 1, 10000, nullptr), "gen");
+  db_ok(dbhip_gen_uniform_u32(bk.get(), n, 44, 0, 1, 10000, nullptr), "gen");
+  db_ok(dbhip_gen_uniform_u32(bv.get(), n, 45, 0, 1, 10000, nullptr), "gen");
+  hip_ok(hipDeviceSynchronize(), "sync");
+  const bool validate = cells <= validate_limit();
+  using Row = std::array<uint32_t, 3>;
+  std::vector<Row> expected;
+  if (validate) {  // join_helpers.hpp:86-104
+    const auto hak = ak.to_host(n), hav = av.to_host(n), hbk = bk.to_host(n), hbv = bv.to_host(n);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < n; ++j)
+        if (hak[i] == hbk[j]) expected.push_back({hak[i], hav[i], hbv[j]});
+  }
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    auto result = std::make_unique<Result>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    db_ok(dbhip_nested_join_u32(ak.get(), av.get(), bk.get(), bv.get(), n, n, ok_.get(), o1.get(), o2.get(), nullptr),
+          "dbhip_nested_join_u32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->kernel_time = ev.elapsed();
+    result->bytes = 12 * cells;
+    if (validate) {
+      const auto hk = ok_.to_host(cells), h1 = o1.to_host(cells), h2 = o2.to_host(cells);
+      std::vector<Row> got;
+      for (size_t c = 0; c < cells; ++c)
+        if (hk[c] != 0u) got.push_back({hk[c], h1[c], h2[c]});
+      if (got != expected) {
+        std::cerr << "Incorrect results" << std::endl;
+        result->valid = false;
+      }
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void NestedLoopJoinHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void NestedLoopJoinHip::init(const RunOptions &opts) { common_init(*this, opts); }

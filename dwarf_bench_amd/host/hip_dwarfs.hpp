@@ -31,5 +31,7 @@ DBHIP_DECLARE_DWARF(JoinHip);
 DBHIP_DECLARE_DWARF(GroupByLocalHip);         // groupby/groupby_local.cpp:24-142 (two-phase timings, --executors)
 DBHIP_DECLARE_DWARF(HashBuildHip);            // hash/hash_build.cpp:8-98 (bitmask-claimed table, build only)
 DBHIP_DECLARE_DWARF(HashBuildNonBitmaskHip);  // hash/hash_build_non_bitmask.cpp:7-91 (CAS table, build only)
+DBHIP_DECLARE_DWARF(ReduceHip);               // reduce/reduce.cpp:27-98 (int sum)
+DBHIP_DECLARE_DWARF(NestedLoopJoinHip);       // join/nested_join.cpp:10-110 (dense cell matrix, small n)
 
 #undef DBHIP_DECLARE_DWARF

@@ -275,6 +275,31 @@ def gather_u32(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+# reduce and nested-loop join (reduce/reduce.cpp, join/nested_join.cpp)
+# ---------------------------------------------------------------------------------------------
+def reduce_sum(src: torch.Tensor) -> torch.Tensor:
+    """one-element int32 tensor: the wrap-around sum of src"""
+    _need(src, torch.int32, "src")
+    out = torch.empty(1, dtype=torch.int32, device=src.device)
+    _capi.check(_capi.lib().dbhip_reduce_sum_i32(src.data_ptr(), src.numel(), out.data_ptr(), _stream()), "reduce_sum_i32")
+    return out
+
+
+def nested_join(a_keys: torch.Tensor, a_vals: torch.Tensor, b_keys: torch.Tensor, b_vals: torch.Tensor):
+    """dense (n_a x n_b) cell matrices (key, a_val, b_val); empty cells are (0, -1, -1)"""
+    for t, name in ((a_keys, "a_keys"), (a_vals, "a_vals"), (b_keys, "b_keys"), (b_vals, "b_vals")):
+        _need(t, torch.int32, name)
+    na, nb = a_keys.numel(), b_keys.numel()
+    if a_vals.numel() != na or b_vals.numel() != nb:
+        raise ValueError("size mismatch")
+    outs = [torch.empty(max(na * nb, 1), dtype=torch.int32, device=a_keys.device) for _ in range(3)]
+    _capi.check(_capi.lib().dbhip_nested_join_u32(a_keys.data_ptr(), a_vals.data_ptr(), b_keys.data_ptr(),
+                                                  b_vals.data_ptr(), na, nb, outs[0].data_ptr(), outs[1].data_ptr(),
+                                                  outs[2].data_ptr(), _stream()), "nested_join_u32")
+    return tuple(o[: na * nb].view(na, nb) if na and nb else o[:0] for o in outs)
+
+
+# ---------------------------------------------------------------------------------------------
 # bitmask-claimed table (SimpleNonOwningHashTable counterpart)
 # ---------------------------------------------------------------------------------------------
 class BitmaskTable:
@@ -304,6 +329,10 @@ class BitmaskTable:
                                                                self.kind, self.seed, vals.data_ptr(), found.data_ptr(),
                                                                _stream()), "bitmask_table_lookup")
         return vals[:n], found[:n]
+
+    def check(self) -> None:
+        """raise if an insert found the table full (DEV_TABLE_FULL)"""
+        _check_status(self.ws, "bitmask_table")
 
     def slot_values(self) -> torch.Tensor:
         """the payload array of the table (for slot-level known-answer tests)"""

@@ -171,6 +171,18 @@ int dbhip_pjoin_partition_u32(const uint32_t *keys, size_t n, uint64_t first_row
 int dbhip_gather_u32(const uint32_t *table, const uint32_t *idx, size_t n, uint32_t *out,
                      dbhip_stream_t stream);
 
+/* ---- the two small dwarfs that complete the taxonomy ---------------------------
+ * dbhip_reduce_sum_i32: *out = sum of src[0..n) with int32 wrap-around (reduce/reduce.cpp:27-88, the
+ *   oneAPI plus<> reduction into an int; the reference's oracle is std::accumulate(..., 0), :10-22).
+ * dbhip_nested_join_u32: the dense n_a x n_b cell matrix of join/nested_join.cpp:52-66, row-major
+ *   over (a row, b row): a matching cell holds (key, a_val, b_val), every other cell holds the
+ *   reference's "empty" markers (key 0, values 0xFFFFFFFF, nested_join.cpp:30-32).  The kernel writes
+ *   all cells, so the three outputs need no initialisation.  n_a <= 1,048,560.                       */
+int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, dbhip_stream_t stream);
+int dbhip_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, const uint32_t *b_keys,
+                          const uint32_t *b_vals, size_t n_a, size_t n_b, uint32_t *out_key,
+                          uint32_t *out_val1, uint32_t *out_val2, dbhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -516,6 +516,33 @@ void dbo_join_bruteforce(const uint32_t *a, size_t na, const uint32_t *b, size_t
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* reduce + nested-loop join */
+int32_t dbo_reduce_sum_i32(const int32_t *src, size_t n) {
+  uint32_t acc = 0; /* reduce.cpp:21 accumulate from 0 */
+  for (size_t i = 0; i < n; ++i) acc += (uint32_t)src[i];
+  return (int32_t)acc;
+}
+
+void dbo_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, size_t na, const uint32_t *b_keys,
+                         const uint32_t *b_vals, size_t nb, uint32_t *out_key, uint32_t *out_v1,
+                         uint32_t *out_v2) {
+  for (size_t c = 0; c < na * nb; ++c) { /* nested_join.cpp:30-32 */
+    out_key[c] = 0;
+    out_v1[c] = 0xFFFFFFFFu;
+    out_v2[c] = 0xFFFFFFFFu;
+  }
+  for (size_t it = 0; it < na; ++it) { /* :56-66, one work-item per A row */
+    const uint32_t key = a_keys[it], val = a_vals[it];
+    for (size_t i = 0; i < nb; ++i)
+      if (b_keys[i] == key) {
+        out_key[it * nb + i] = key;
+        out_v1[it * nb + i] = val;
+        out_v2[it * nb + i] = b_vals[i];
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* unique-key payload join */
 size_t dbo_seq_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, size_t na,
                         const uint32_t *b_keys, const uint32_t *b_vals, size_t nb, uint32_t *out_key,
@@ -557,6 +584,12 @@ uint32_t dbo_bitmask_table_insert(dbo_bitmask_table *t, uint32_t key, uint32_t v
   uint32_t minor = at % elem_sz;
   uint32_t pos;
   for (;;) {
+    if ((size_t)major * elem_sz + minor >= t->size) { /* ragged last word: the reference would claim a slot
+                                                       * >= size here (out of bounds); wrap instead */
+      major = 0;
+      minor = 0;
+      continue;
+    }
     uint32_t mask = 1u << minor;
     uint32_t present = __atomic_fetch_or(&t->bitmask[major], mask, __ATOMIC_RELAXED);
     if (!(present & mask)) {
@@ -565,7 +598,7 @@ uint32_t dbo_bitmask_table_insert(dbo_bitmask_table *t, uint32_t key, uint32_t v
     }
     uint32_t inv = ~(present >> minor);
     uint32_t occupied = inv ? (uint32_t)__builtin_ctz(inv) : 32u;
-    if (occupied + minor >= elem_sz || (size_t)major * elem_sz + minor >= t->size) {
+    if (occupied + minor >= elem_sz) {
       major = (uint32_t)((major + 1) % t->bitmask_sz);
       minor = 0;
     } else {

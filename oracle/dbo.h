@@ -91,6 +91,15 @@ void dbo_join_bruteforce(const uint32_t *a, size_t na, const uint32_t *b, size_t
                          size_t *off_out, size_t *ids_out);
 
 /* ---- unique-key payload join ---------------------------------------------------------------- */
+/* reduce/reduce.cpp:10-22 expected_out: std::accumulate(v.begin(), v.end(), 0) in int — restated with
+ * unsigned wrap-around so the result is defined for every input (the reference asserts its inputs
+ * cannot overflow, :13-19; on those inputs the two agree).
+ * join/nested_join.cpp:52-66: the dense cell matrix, pre-filled with (0, 0xFFFFFFFF, 0xFFFFFFFF) (:30-32). */
+int32_t dbo_reduce_sum_i32(const int32_t *src, size_t n);
+void dbo_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, size_t na, const uint32_t *b_keys,
+                         const uint32_t *b_vals, size_t nb, uint32_t *out_key, uint32_t *out_v1,
+                         uint32_t *out_v2);
+
 /* join/join_helpers/join_helpers.hpp:86-104 seq_join (a-major, b-minor).  Returns rows written
  * (outputs sized na*nb worst case by the caller, or NULL to only count). */
 size_t dbo_seq_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, size_t na,

@@ -241,6 +241,23 @@ def seq_join(a_keys, a_vals, b_keys, b_vals):
     return ok[:n], o1[:n], o2[:n]
 
 
+def reduce_sum(src) -> int:
+    a = _i32a(src)
+    f = lib().dbo_reduce_sum_i32
+    f.restype = C.c_int32
+    return int(f(_p(a), _sz(a.size)))
+
+
+def nested_join(a_keys, a_vals, b_keys, b_vals):
+    """dense (na x nb) cell matrices, reference markers in the empty cells"""
+    ak, av, bk, bv = map(_u32a, (a_keys, a_vals, b_keys, b_vals))
+    outs = [np.empty(max(ak.size * bk.size, 1), dtype=np.uint32) for _ in range(3)]
+    f = lib().dbo_nested_join_u32
+    f.restype = None
+    f(_p(ak), _p(av), _sz(ak.size), _p(bk), _p(bv), _sz(bk.size), *map(_p, outs))
+    return tuple(o[: ak.size * bk.size].reshape(ak.size, bk.size) for o in outs)
+
+
 def ujoin(a_keys, a_vals, b_keys, b_vals, seed: int = 7):
     """join.cpp:60-131 through the bitmask table: per-probe-row outputs with 0xFFFFFFFF sentinels."""
     ak, av, bk, bv = map(_u32a, (a_keys, a_vals, b_keys, b_vals))

@@ -117,3 +117,40 @@ def test_duplicate_keys_all_found():
     vals, found = t.lookup(_dev(keys))
     assert bool((found == 1).all())
     assert np.array_equal(vals.cpu().numpy().view(np.uint32), keys)
+
+
+def test_ragged_last_word_wraps_instead_of_leaving_the_table():
+    """size % 32 != 0: a run reaching the end continues at slot 0 (hashtable.hpp:83-85); the reference's
+    `minor += occupied` could step past `size` there, oracle and kernel wrap instead"""
+    from dwarf_bench_amd import ops
+    size = 70
+    ins = [(69, 1), (69, 2), (69, 3), (5, 4), (139, 5), (68, 6), (68, 7)]
+    want = po.BitmaskTable(size, 0, 0)
+    slots = [want.insert(k, v) for k, v in ins]
+    assert slots == [69, 0, 1, 5, 2, 68, 3] and max(slots) < size
+    t = ops.BitmaskTable(size, hash_kind=0)
+    arr = np.array(ins, dtype=np.uint32)
+    t.insert(_dev(arr[:, 0]), _dev(arr[:, 1]), serial=True)
+    t.check()
+    assert np.array_equal(t.slot_values().cpu().numpy().view(np.uint32), want.data())
+    vals, found = t.lookup(_dev([69, 139, 68, 5, 70]))
+    assert found.cpu().tolist() == [1, 1, 1, 1, 0] and vals.cpu().tolist()[:4] == [1, 5, 6, 4]
+    # the same rows inserted concurrently: every slot stays inside the table, every key is found
+    t2 = ops.BitmaskTable(size, hash_kind=0)
+    t2.insert(_dev(arr[:, 0]), _dev(arr[:, 1]))
+    t2.check()
+    assert bool((t2.lookup(_dev(arr[:, 0]))[1] == 1).all())
+
+
+@pytest.mark.parametrize("size", [64, 70, 1000])
+def test_fill_to_capacity_then_overflow_is_reported(size):
+    from dwarf_bench_amd import _capi, ops
+    t = ops.BitmaskTable(size, 1, 3)
+    keys = np.arange(1, size + 1, dtype=np.uint32)
+    t.insert(_dev(keys), _dev(keys))
+    t.check()
+    vals, found = t.lookup(_dev(keys))
+    assert bool((found == 1).all()) and np.array_equal(vals.cpu().numpy().view(np.uint32), keys)
+    t.insert(_dev([size + 1]), _dev([0]))  # no free slot: the reference would spin forever
+    with pytest.raises(_capi.DbhipError):
+        t.check()

@@ -177,3 +177,17 @@ def _load_mix():
 
 
 _load_mix()
+
+
+def test_reduce_and_nested_join_restatements(kats):
+    """reduce.cpp:10-22 (accumulate) and nested_join.cpp:52-90 (dense cells, compacted = seq_join order)"""
+    src = po.gen_uniform_u32(5000, 42, 1, 10000).view(np.int32)
+    assert po.reduce_sum(src) == int(src.astype(np.int64).sum())
+    assert po.reduce_sum(np.array([2**31 - 1, 1], dtype=np.int32)) == -(2**31)
+    f = kats["seq_join_fixture"]
+    k, v1, v2 = po.nested_join(f["keys_a"], f["vals_a"], f["keys_b"], f["vals_b"])
+    assert k.shape == (7, 7) and int((k == 0).sum()) == 49 - 8
+    assert bool((v1[k == 0] == 0xFFFFFFFF).all()) and bool((v2[k == 0] == 0xFFFFFFFF).all())
+    keep = k.reshape(-1) != 0
+    rows = list(zip(k.reshape(-1)[keep].tolist(), v1.reshape(-1)[keep].tolist(), v2.reshape(-1)[keep].tolist()))
+    assert [list(r) for r in rows] == f["expected_rows"]

@@ -70,6 +70,39 @@ def main():
             t = bmed + pmed
             print(f"join n=2^{lg}: build {bmed:.0f} us probe {pmed:.0f} us total {t:.0f} us  {2*n/t:.0f} Mrows/s  20N-roofline {20*n/t/1e6/8*100:.2f}%")
             del plan
+    if "reduce" in which:
+        for lg in (20, 24, 28):
+            n = 1 << lg
+            src = ops.gen_uniform_u32(n, 42, 1, 10000)
+            mn, med = timeit(lambda: ops.reduce_sum(src))
+            print(f"reduce n=2^{lg}: min {mn:.1f} med {med:.1f} us  {n/med:.0f} Mrows/s  {4*n/med/1e6:.3f} TB/s ({4*n/med/1e6/8*100:.1f}%)")
+    if "hashbuild" in which:
+        for lg in (20, 24, 26):
+            n = 1 << lg
+            keys = ops.gen_uniform_u32(n, 42, 1, 10000)
+            t = ops.BitmaskTable(2 * n, 1, 421)
+            def run():
+                t.reset()
+                t.insert(keys, keys)
+            mn, med = timeit(run, iters=5, warm=1)
+            rmn, rmed = timeit(t.reset, iters=5, warm=1)
+            print(f"hashbuild(bitmask, dup keys) n=2^{lg}: med {med - rmed:.0f} us (+reset {rmed:.0f})  {n/(med-rmed):.0f} Mrows/s")
+            ukeys = ops.gen_unique_sorted_u32(n, 42) if n <= (1 << 28) else keys
+            def run2():
+                t.reset()
+                t.insert(ukeys, ukeys)
+            mn, med = timeit(run2, iters=5, warm=1)
+            print(f"hashbuild(bitmask, unique keys) n=2^{lg}: med {med - rmed:.0f} us  {n/(med-rmed):.0f} Mrows/s")
+            uj = ops.UniqueJoin(n, n)
+            mn, med = timeit(lambda: uj.build(ukeys, ukeys), iters=5, warm=1)
+            print(f"hashbuild(CAS, unique keys) n=2^{lg}: med {med:.0f} us  {n/med:.0f} Mrows/s")
+            del t, uj
+    if "nlj" in which:
+        for n in (1024, 4096, 16384):
+            a = ops.gen_uniform_u32(n, 42, 1, 10000)
+            b = ops.gen_uniform_u32(n, 44, 1, 10000)
+            mn, med = timeit(lambda: ops.nested_join(a, a, b, b), iters=5, warm=1)
+            print(f"nested join n={n}: med {med:.1f} us  {12*n*n/med/1e6:.3f} TB/s written")
 
 
 if __name__ == "__main__":
