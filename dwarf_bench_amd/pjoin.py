@@ -6,11 +6,18 @@ Per rank, with local shards of the build (R) and probe (S) key columns and their
                 bucket-major (key, global row id) pairs + per-bucket counts;
   2. counts     one all_to_all of the P-entry count vectors (who sends how much to whom);
   3. exchange   all_to_all of the pairs (RCCL: every GPU sends 1/P of its rows to each peer, one peer per
-                xGMI link, all links busy at once) — keys and row ids of one relation travel as one
-                int32 [n, 2]... two columns, one collective per column;
+                xGMI link, all links busy at once), one collective per column (keys, row ids);
   4. local join dwarf 4a on the received pairs (dbhip_join_build_pairs_u32 / dbhip_join_probe_u32): the id
                 buffer holds GLOBAL build row ids.
 Results stay sharded by key hash: per rank (probe global row id, offset, count) + the id buffer.
+
+The steps of the two relations are interleaved so that the xGMI exchange hides behind HBM-bound kernels
+(collectives are issued async: they run on RCCL's own stream, `wait()` only makes the compute stream wait):
+
+    compute stream :  partition R |            partition S | build R            | probe S
+    RCCL stream    :          counts R | exchange R | counts S | exchange S |
+
+The host blocks twice, on the two tiny count exchanges (split sizes must be host integers).
 
 The compute steps go through a small backend object so that the orchestration (split sizes, collectives,
 bookkeeping) can be exercised on CPU/gloo in tests with a test-only backend; the product backend is
@@ -31,13 +38,20 @@ class HipBackend:
         from . import ops
         return ops.partition_by_hash(keys, first_row_id, parts)
 
-    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None):
-        """-> pos, cnt, ids; ids hold build_row_ids values when given (global row ids), else local indices"""
+    def build(self, build_keys: torch.Tensor, build_row_ids: torch.Tensor | None, n_probe: int):
+        """-> plan; the id buffer holds build_row_ids values when given (global row ids), else local indices"""
         from . import ops
-        plan = ops.HashJoin(build_keys.numel(), probe_keys.numel(), build_keys.device)
+        plan = ops.HashJoin(build_keys.numel(), n_probe, build_keys.device)
         plan.build(build_keys, build_row_ids)
+        return plan
+
+    def probe(self, plan, probe_keys: torch.Tensor):
+        """-> pos, cnt, ids"""
         plan.probe(probe_keys)
         return plan.result()
+
+    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None):
+        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
 
 
 @dataclass
@@ -51,22 +65,50 @@ class PartitionedJoinResult:
     recv_probe_rows: int
 
 
-def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
-    """all_to_all_single; a gloo group (CPU rehearsal of the exchange) only moves host memory, so device
-    tensors are staged through the host there.  With the nccl (= RCCL) backend this is one collective on
-    device memory over xGMI."""
+class _Done:
+    """handle of an exchange that has already completed"""
+
+    def __init__(self, out):
+        self.out = out
+
+    def wait(self):
+        return self.out
+
+
+class _Pending:
+    """handle of a collective in flight on the backend's own stream; wait() orders the current stream after it"""
+
+    def __init__(self, work, out, keep):
+        self.work, self.out, self.keep = work, out, keep  # `keep`: the send buffer must outlive the collective
+
+    def wait(self):
+        self.work.wait()
+        self.keep = None
+        return self.out
+
+
+def _a2a(inp: torch.Tensor, out_splits, in_splits, group):
+    """all_to_all_single -> handle.  With the nccl (= RCCL) backend this is one async collective on device
+    memory over xGMI.  A gloo group (CPU rehearsal of the exchange) only moves host memory, so device tensors
+    are staged through the host there, synchronously."""
+    n_out = int(sum(out_splits)) if out_splits is not None else inp.numel()
+    inp = inp.contiguous()
     if inp.is_cuda and dist.get_backend(group) == "gloo":
-        host_out = torch.empty(out.shape, dtype=out.dtype)
+        host_out = torch.empty(n_out, dtype=inp.dtype)
         dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-        out.copy_(host_out)
-        return
-    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        return _Done(host_out.to(inp.device))
+    out = torch.empty(n_out, dtype=inp.dtype, device=inp.device)
+    work = dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                  async_op=True)
+    return _Pending(work, out, inp)
 
 
-def _exchange(column: torch.Tensor, send_counts, recv_counts, group) -> torch.Tensor:
-    out = torch.empty(int(sum(recv_counts)), dtype=column.dtype, device=column.device)
-    _a2a(out, column.contiguous(), [int(x) for x in recv_counts], [int(x) for x in send_counts], group)
-    return out
+def _exchange_counts(counts: torch.Tensor, group):
+    """counts: this rank's P send counts (device or host int64/uint64).  One tiny all_to_all tells every rank what
+    it will receive.  -> (send, recv) as host int lists — blocks the host until `counts` is computed and exchanged."""
+    send = counts.to(torch.int64)
+    recv = _a2a(send, None, None, group).wait()
+    return [int(x) for x in send.cpu().tolist()], [int(x) for x in recv.cpu().tolist()]
 
 
 def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_first_row: int, probe_first_row: int,
@@ -82,29 +124,20 @@ def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_f
         ids_global = ids if build_first_row == 0 else (ids.to(torch.int64) + build_first_row).to(torch.int32)
         return PartitionedJoinResult(rid, pos, cnt, ids_global, 0, build_keys.numel(), probe_keys.numel())
 
+    # R: partition, learn the split sizes, start its exchange
     rk, rr, rc = backend.partition(build_keys, build_first_row, world)
+    r_send, r_recv = _exchange_counts(rc, group)
+    rk_x = _a2a(rk, r_recv, r_send, group)
+    rr_x = _a2a(rr, r_recv, r_send, group)
+    # S: partition while R is on the links
     sk, sr, sc = backend.partition(probe_keys, probe_first_row, world)
-    # counts matrix: row = sender.  One small all_to_all tells every rank what it will receive.
-    send_counts = torch.stack([rc, sc]).to(torch.int64)           # [2, P]
-    recv_flat = torch.empty(2 * world, dtype=torch.int64, device=send_counts.device)
-    _a2a(recv_flat, _interleave(send_counts, world), None, None, group)
-    recv_counts = _deinterleave(recv_flat, world)
-    send_h, recv_h = send_counts.cpu().tolist(), recv_counts.cpu().tolist()  # split sizes must be host ints
-
-    rk_in = _exchange(rk, send_h[0], recv_h[0], group)
-    rr_in = _exchange(rr, send_h[0], recv_h[0], group)
-    sk_in = _exchange(sk, send_h[1], recv_h[1], group)
-    sr_in = _exchange(sr, send_h[1], recv_h[1], group)
-
-    pos, cnt, ids_global = backend.local_join(rk_in, sk_in, rr_in)
-    sent = int(sum(send_h[0]) - send_h[0][rank] + sum(send_h[1]) - send_h[1][rank])
+    s_send, s_recv = _exchange_counts(sc, group)
+    sk_x = _a2a(sk, s_recv, s_send, group)
+    sr_x = _a2a(sr, s_recv, s_send, group)
+    # build on the received R pairs while S is on the links, then probe
+    rk_in, rr_in = rk_x.wait(), rr_x.wait()
+    plan = backend.build(rk_in, rr_in, int(sum(s_recv)))
+    sk_in, sr_in = sk_x.wait(), sr_x.wait()
+    pos, cnt, ids_global = backend.probe(plan, sk_in)
+    sent = int(sum(r_send) - r_send[rank] + sum(s_send) - s_send[rank])
     return PartitionedJoinResult(sr_in, pos, cnt, ids_global, sent, rk_in.numel(), sk_in.numel())
-
-
-def _interleave(counts: torch.Tensor, world: int) -> torch.Tensor:
-    """[2, P] -> flat [P*2] with the two relations' counts for peer p adjacent (one all_to_all of 2 ints per peer)"""
-    return counts.t().contiguous().view(-1)
-
-
-def _deinterleave(flat: torch.Tensor, world: int) -> torch.Tensor:
-    return flat.view(world, 2).t().contiguous()

@@ -33,7 +33,11 @@ class OracleBackend:
         return (torch.from_numpy(k[order].view(np.int32).copy()), torch.from_numpy(rid[order].view(np.int32).copy()),
                 torch.from_numpy(counts))
 
-    def local_join(self, build_keys, probe_keys, build_row_ids=None):
+    def build(self, build_keys, build_row_ids, n_probe):
+        return (build_keys, build_row_ids)
+
+    def probe(self, plan, probe_keys):
+        build_keys, build_row_ids = plan
         b = build_keys.numpy().view(np.uint32)
         p = probe_keys.numpy().view(np.uint32)
         pos, cnt, ids = po.join_omnisci(b, p)
@@ -41,6 +45,9 @@ class OracleBackend:
             ids = build_row_ids.numpy().view(np.uint32)[ids.astype(np.int64)]
         t = lambda a: torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
         return t(pos), t(cnt), t(ids)
+
+    def local_join(self, build_keys, probe_keys, build_row_ids=None):
+        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
 
 
 def check_global(results, build_all: np.ndarray, probe_all: np.ndarray):
