@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X dwarf backend.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dwarf scan|sort|groupby|join|all] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dwarf scan|sort|groupby|join|all] [--no-cpu] [--no-pjoin]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM.
 N = 1 (default): the configuration BASELINE.json's metric is quoted on — TwoPassScan (stream compaction
 x < 5 over int32 uniform in [1, 10000]) at 2^28 rows.  The other single-GPU configurations of BASELINE.json
 (radix sort 2^24, group-by 2^26 rows / 2^16 groups, hash join 2^26 x 2^26) are measured in the same run with
 a few steps each and reported under "dwarfs" (they are not the headline value).
-N > 1 (launched by torch.distributed.run, one rank per GPU): see MULTI-GPU below.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the headline stays the same metric — scan does not
+shard ("replicas only"), so every rank runs the 2^28 scan on its own GPU and `value` is the aggregate (weak
+scaling) — and the one part of the path that does shard, the radix-partitioned hash join 2^30 x 2^30 with its
+RCCL all-to-all, is measured in the same run (strong scaling) and reported under "pjoin" together with its
+single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.
+Rehearsal knobs (not for reported numbers): DBENCH_BACKEND=gloo lets several ranks share one GPU,
+DBENCH_PJOIN_LOG2 shrinks the partitioned join.
 
 Prints ONE JSON line on rank 0 with the contract fields plus "roofline" and "cpu_baseline".
 The oracle (oracle/) is used ONLY for the cpu_baseline leg and a one-off result check; the timed path is
@@ -162,7 +168,7 @@ def bench_join(steps, warmup, log2n=26):
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 
-def bench_pjoin(steps, warmup, log2_total=30, dist=None):
+def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
     """Radix-partitioned hash join of 2^log2_total x 2^log2_total rows over all ranks (strong scaling: the total
     is fixed, every rank holds a contiguous 1/P shard of both key columns, generated in place)."""
     import torch
@@ -181,13 +187,18 @@ def bench_pjoin(steps, warmup, log2_total=30, dist=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # `group`: with dist=None inside a multi-rank job, a one-rank group that makes this call a plain local join.
+    # The previous result is dropped before each step so the caching allocator reuses its blocks: holding it
+    # alive forces fresh hipMallocs of tens of GiB inside the timed region (measured: 2.9 s instead of 70 ms).
     res = None
     for _ in range(warmup):
-        res = pjoin.partitioned_join(build, probe, lo, lo)
+        res = None
+        res = pjoin.partitioned_join(build, probe, lo, lo, group=group)
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = pjoin.partitioned_join(build, probe, lo, lo)
+        res = None
+        res = pjoin.partitioned_join(build, probe, lo, lo, group=group)
     sync()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     if dist is not None:
@@ -239,43 +250,33 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dwarf", default="all", choices=["all", "scan", "sort", "groupby", "join"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pjoin", action="store_true", help="skip the single-GPU 2^30 x 2^30 join (profiling passes)")
     args = ap.parse_args()
 
     rank, world, local = _dist_env()
+    if os.environ.get("DBENCH_FAULT_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DBENCH_FAULT_DUMP"]), exit=True)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if os.environ.get("DBENCH_BACKEND", "nccl") != "nccl":  # rehearsal: ranks may share a GPU
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("DBENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     n_gpus = max(world, 1)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    if n_gpus > 1:
-        # ---- MULTI-GPU: the one path of the hot path that shards (BASELINE north_star): the hash join,
-        # radix-partitioned across the ranks with an RCCL all-to-all bucket exchange.  Total work is fixed.
-        pj = bench_pjoin(max(1, min(args.steps, 5)), max(1, min(args.warmup, 2)), 30, dist)
-        if rank == 0:
-            print(json.dumps({
-                "metric": "Mrows/s, radix-partitioned hash join 2^30 x 2^30 (build+probe rows / s, all GPUs)",
-                "value": pj["mrows_per_s"], "unit": "Mrows/s", "n_gpus": n_gpus, "steps": max(1, min(args.steps, 5)),
-                "warmup": max(1, min(args.warmup, 2)), "ms_per_step": pj["ms_per_step"], "higher_is_better": True,
-                "scaling": "strong", "vs_baseline": None, "dtype": "uint32", "data": "synthetic",
-                "config": {"workload": pj["workload"], "rows": pj["rows"], "parallelism": f"hash-partitioned over {n_gpus} ranks, "
-                           "all_to_all bucket exchange (RCCL over xGMI), local open-addressing join per rank",
-                           "single_gpu_reference": "the N=1 line of this bench reports the same join on one GPU under dwarfs.pjoin_p1"},
-                "roofline": None, "cpu_baseline": None,
-                "pjoin": {k: v for k, v in pj.items() if k != "workload"},
-            }))
-        dist.barrier()
-        dist.destroy_process_group()
-        return
 
     # ---- headline: scan 2^28 (BASELINE.json's metric configuration)
     barrier()
@@ -312,7 +313,7 @@ def main():
             out["parity_check"] = bool(np.array_equal(got, po.copy_if_lt(scan["src"][:m].cpu().numpy(), 5)))
         except Exception as e:  # pragma: no cover
             out["parity_check"] = f"skipped: {e}"
-        if not args.no_cpu:
+        if not args.no_cpu and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline_scan(scan["src"], 5)
         else:
             out["cpu_baseline"] = None
@@ -330,9 +331,40 @@ def main():
         if args.dwarf in ("all", "join"):
             dwarfs["join"] = bench_join(max(3, k // 2), 2)
             torch.cuda.empty_cache()
-            pj = bench_pjoin(2, 1, 30, None)  # the single-GPU reference point of the multi-GPU line
-            dwarfs["pjoin_p1"] = {k2: v for k2, v in pj.items()}
+            if not args.no_pjoin:
+                pj = bench_pjoin(2, 1, 30, None)  # the single-GPU point of the partitioned join's scaling curve
+                dwarfs["pjoin_p1"] = {k2: v for k2, v in pj.items()}
+        for name, d in dwarfs.items():  # HBM bytes per call from the committed PMC passes, where collected
+            t = _traffic_for(name)
+            if t is not None:
+                d["pmc_traffic_bytes"] = t
         out["dwarfs"] = dwarfs
+
+    if n_gpus > 1:
+        # ---- the one part of the hot path that shards (BASELINE north_star): the hash join, radix-partitioned
+        # across the ranks with an RCCL all-to-all bucket exchange.  STRONG scaling: 2^30 x 2^30 in total whatever N
+        # is.  Its single-GPU reference point is measured in this same run, on rank 0's GPU, while the other ranks
+        # wait — so the speed-up is self-contained in this line.
+        torch.cuda.empty_cache()
+        pj_steps, pj_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+        pj_log2 = int(os.environ.get("DBENCH_PJOIN_LOG2", "30"))
+        pj = bench_pjoin(pj_steps, pj_warm, pj_log2, dist)
+        torch.cuda.empty_cache()
+        solo = dist.new_group(ranks=[0])  # collective call; only rank 0 uses it: its join below is purely local
+        p1 = bench_pjoin(2, 1, pj_log2, None, group=solo) if rank == 0 else None
+        barrier()
+        if rank == 0:
+            out["pjoin"] = {
+                "metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
+                "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm,
+                "parallelism": f"hash-partitioned over {n_gpus} ranks, all_to_all bucket exchange (RCCL over xGMI) "
+                               "overlapped with partition/build, local LDS-partitioned join per rank",
+                **{k: v for k, v in pj.items()},
+                "bytes_sent_per_gpu": pj["rows_exchanged"] * 8 / n_gpus,
+                "single_gpu_ms_per_step": p1["ms_per_step"], "single_gpu_mrows_per_s": p1["mrows_per_s"],
+                "speedup_vs_1gpu": p1["ms_per_step"] / pj["ms_per_step"],
+                "matches_equal_single_gpu": pj["matches"] == p1["matches"],
+            }
 
     if rank == 0:
         print(json.dumps(out))

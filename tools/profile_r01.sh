@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence bench.py's numbers are judged against (run on the GPU box, from the repo root):
+#   1. --kernel-trace --stats of the bench command itself (per-kernel average durations)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own passes (HBM traffic per launch)
+# Raw output goes to gpurun_out/prof_<tag>/; tools/profile_summary.py condenses it into profiles/.
+set -euo pipefail
+tag="${1:-r01}"
+repo="$(pwd)"
+out="$repo/gpurun_out/prof_$tag"
+mkdir -p "$out"
+cd /tmp
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python3 "$repo/bench.py" --steps 20 --warmup 3 --no-cpu > "$out/bench_under_kt.log" 2>&1
+echo "[profile] kernel trace done"
+rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin > "$out/bench_under_pmc_fetch.log" 2>&1
+echo "[profile] FETCH_SIZE done"
+rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin > "$out/bench_under_pmc_write.log" 2>&1
+echo "[profile] WRITE_SIZE done"
+cd "$repo"
+python3 tools/profile_summary.py "$out" "$tag"
