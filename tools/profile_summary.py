@@ -25,8 +25,9 @@ DWARFS = {
     "sort_8bit": (r"rs_\w+<8", r"rs_histogram", True),
     "sort_4bit": (r"rs_\w+<4", r"rs_histogram", True),
     "groupby": (r"gb_aggregate_kernel|gb_reduce_kernel", r"gb_aggregate_kernel", True),
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel", r"jl_build_kernel", True),
-    "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", True),
+    # join: 4-B/lane reads and random 16-B gathers — widths the guide calls uncalibrated: raw counter, not doubled
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel", r"jl_build_kernel", False),
+    "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", False),
 }
 
 
@@ -89,7 +90,7 @@ def main():
         read_b = rd * 1024 * (2 if dbl else 1) / calls_r
         write_b = wr * 1024 / calls_w
         traffic[dwarf] = {"hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
-                          "calls_seen": calls_r}
+                          "calls_seen": calls_r, "fetch_size_doubled": dbl}
     if "join_build" in traffic and "join_probe" in traffic:
         traffic["join"] = {k: traffic["join_build"][k] + traffic["join_probe"][k]
                            for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes")}
