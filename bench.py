@@ -242,6 +242,55 @@ def cpu_baseline_scan(src_dev, filt, budget_s=12.0):
             "single_thread_mrows_per_s": m1 / t1 / 1e6}
 
 
+def cpu_baselines_dwarfs(which):
+    """CPU baselines of the other dwarfs: the oracle's multi-threaded restatements of the reference
+    algorithms on bounded samples of the same synthetic columns, all host cores.  Reported, never a target."""
+    import numpy as np
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    out = {}
+    if "sort" in which:
+        n = 1 << 24
+        keys0 = po.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+        tmp = np.empty_like(keys0)
+        best, reps, t_total = None, 0, 0.0
+        while t_total < 4.0 and reps < 20:
+            k = keys0.copy()
+            t0 = time.perf_counter()
+            po.radix_sort_u32_mt(k, tmp, cores)
+            dt = time.perf_counter() - t0
+            t_total += dt
+            reps += 1
+            best = dt if best is None else min(best, dt)
+        out["sort"] = {"value": n / (t_total / reps) / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port",
+                       "sample": f"the full 2^24 full-range keys, {reps} sorts (oracle dbo_radix_sort_u32_mt: parallel LSD "
+                                 f"radix, the role TBBSort/std::sort play in sort/tbbsort.cpp:22, sort/radix.cpp:8-12)"}
+    if "groupby" in which:
+        n, groups = 1 << 24, 1 << 16
+        keys = po.gen_uniform_u32(n, 42, 0, groups - 1)
+        vals = po.gen_uniform_u32(n, 43, 1, 10000)
+        reps, t_total = 0, 0.0
+        while t_total < 4.0 and reps < 20:
+            t0 = time.perf_counter()
+            po.groupby_hash(keys, vals, groups, threads=cores)
+            t_total += time.perf_counter() - t0
+            reps += 1
+        out["groupby"] = {"value": n / (t_total / reps) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
+                          "sample": f"first 2^24 rows of the same columns, 2^16 groups, {reps} passes (oracle "
+                                    f"dbo_groupby_hash_u32 = CAS + fetch_add table of groupby/groupby.cpp:58-93, "
+                                    f"hashtable.hpp:136-153)"}
+    if "join" in which:
+        n = 1 << 22
+        build = po.gen_uniform_u32(n, 42, 0, (1 << 26) - 1)  # the first 2^22 rows of the 2^26 columns
+        probe = po.gen_uniform_u32(n, 43, 0, (1 << 26) - 1)
+        bs, ps, _ = po.join_omnisci_timings(build, probe, cores)
+        out["join"] = {"value": 2 * n / (bs + ps) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
+                       "build_s": bs, "probe_s": ps,
+                       "sample": "first 2^22 rows of both 2^26 key columns, one build + probe (oracle dbo_join_build/"
+                                 "dbo_join_probe = omnisci_hashtable.hpp:80-192 with std::atomic)"}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -334,6 +383,10 @@ def main():
             if not args.no_pjoin:
                 pj = bench_pjoin(2, 1, 30, None)  # the single-GPU point of the partitioned join's scaling curve
                 dwarfs["pjoin_p1"] = {k2: v for k2, v in pj.items()}
+        if not args.no_cpu:
+            want = [w for w in ("sort", "groupby", "join") if args.dwarf in ("all", w)]
+            for name, base in cpu_baselines_dwarfs(want).items():
+                dwarfs["sort_8bit" if name == "sort" else name]["cpu_baseline"] = base
         for name, d in dwarfs.items():  # HBM bytes per call from the committed PMC passes, where collected
             t = _traffic_for(name)
             if t is not None:

@@ -14,6 +14,8 @@ constexpr int kWave = 64;
 // native 16-byte vectors (clang ext_vector_type: usable with __builtin_nontemporal_load/store)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));  // 16-byte access at 8-byte alignment
 constexpr size_t kWsAlign = 256;   // workspace alignment required from callers
 constexpr size_t kWsHeader = 256;  // [0] status word, rest reserved; cleared by every call
 

@@ -41,7 +41,8 @@ inline JlLayout jl_layout(size_t n) {
   L.k1 = L.parts / L.k2;
   const size_t col = align_up((n ? n : 1) * sizeof(unsigned), kWsAlign);
   L.table_off = kWsHeader;
-  L.keys_a_off = L.table_off + static_cast<size_t>(L.parts) * kJlSubSlots * 16;
+  // 8-byte slots {key, first id position} + one sentinel slot after the last sub-table
+  L.keys_a_off = align_up(L.table_off + (static_cast<size_t>(L.parts) * kJlSubSlots + 1) * 8, kWsAlign);
   L.rids_a_off = L.keys_a_off + col;
   L.keys_b_off = L.rids_a_off + col;
   L.rids_b_off = L.keys_b_off + (L.k2 > 1 ? col : 0);

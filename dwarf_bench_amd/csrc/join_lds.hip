@@ -12,10 +12,15 @@
 //          2. one workgroup per partition (jl_build): 4096-slot sub-table in LDS — ds_cmpst claim of
 //             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
 //             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
-//             as 16-byte slots {key, count, first id position, -} — the global table is the
-//             concatenation of the sub-tables;
-//   probe  one 16-byte gather per probe row (partition from the high hash bits, slot from the low
-//          bits, linear probing inside the 4096-slot sub-table), outputs written coalesced in row order.
+//             as 8-byte slots {key, first id position} — EVERY slot, empty ones included, carries the
+//             position the exclusive scan reached there, and positions run on from one sub-table to the
+//             next (the global table is the concatenation of the sub-tables plus one sentinel slot
+//             {empty, n}), so a key's match count is first_position[slot + 1] - first_position[slot]
+//             and needs no field of its own: the table write, the largest item of the build's traffic,
+//             is 16n bytes instead of 32n;
+//   probe  one 16-byte gather per probe row = the slot and its right-hand neighbour (partition from the
+//          high hash bits, slot from the low bits, linear probing inside the 4096-slot sub-table),
+//          outputs written coalesced in row order.
 // A partition may hold any number of rows (duplicates do not matter); it may hold at most 4096
 // DISTINCT keys — with 2048 rows expected per partition and a mixing hash that is out of reach for
 // real data; if it happens the build sets DBHIP_DEV_TABLE_FULL.
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
 __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
-                                                                   u32x4 *__restrict__ table,
+                                                                   u32x2 *__restrict__ table, unsigned parts,
+                                                                   unsigned n_rows,
                                                                    unsigned *__restrict__ ids, unsigned *status) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
   unsigned *lk = s_lds;                  // keys
@@ -367,31 +373,30 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = prids[i];
   }
   __syncthreads();
-  // 4. publish the sub-table: {key, count, first position, 0}
-  u32x4 *dst = table + part * kJlSubSlots;
-  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
-    const unsigned cnt = lc[i];
-    dst[i] = u32x4{lk[i], cnt, lp[i] - cnt, 0u};
-  }
+  // 4. publish the sub-table: {key, first position} for every slot (the fill bumped lp[] by the count)
+  u32x2 *dst = table + part * kJlSubSlots;
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) dst[i] = u32x2{lk[i], lp[i] - lc[i]};
+  if (part + 1 == parts && tid == 0) dst[kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // right neighbour of the last slot
 }
 
 __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
-                                                              const u32x4 *__restrict__ table, unsigned parts,
+                                                              const u32x2 *__restrict__ table, unsigned parts,
                                                               unsigned *__restrict__ out_pos,
                                                               unsigned *__restrict__ out_cnt) {
   // one row per lane per step at full occupancy (32 waves per CU): the probe is pure memory latency,
-  // one random 16-byte line per row; unrolling rows per lane measured slower (2.1 vs 1.7 ms at 2^26)
+  // one random 16-byte gather per row (slot + right neighbour, 8-byte aligned: global_load_dwordx4 needs
+  // no more); unrolling rows per lane measured slower (2.1 vs 1.7 ms at 2^26)
   const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
     const unsigned key = probe[i];
     const unsigned h = fmix32(key);
-    const u32x4 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+    const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
     unsigned s = h & kJlSubMask, pos = 0, cnt = 0;
     for (unsigned tries = 0; tries <= kJlSubMask; ++tries) {
-      const u32x4 e = sub[s];
+      const u32x4 e = *reinterpret_cast<const u32x4_a8 *>(sub + s);  // {key, first, next slot's key, next slot's first}
       if (e.x == key) {
-        cnt = e.y;
-        pos = e.z;
+        pos = e.y;
+        cnt = e.w - e.y;
         break;
       }
       if (e.x == kEmptyKey) break;
@@ -416,7 +421,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const JlLayout L = jl_layout(n);
   char *base = static_cast<char *>(workspace);
   unsigned *status = reinterpret_cast<unsigned *>(base);
-  u32x4 *table = reinterpret_cast<u32x4 *>(base + L.table_off);
+  u32x2 *table = reinterpret_cast<u32x2 *>(base + L.table_off);
   unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);
   unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);
   unsigned *k_b = reinterpret_cast<unsigned *>(base + L.keys_b_off);
@@ -466,7 +471,8 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, pk, pr, pstarts, table, ids,
+  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, pk, pr, pstarts, table, L.parts,
+                     static_cast<unsigned>(n), ids,
                      status);
   return launch_status();
 }
@@ -474,7 +480,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
 int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *workspace, size_t n_build,
                    unsigned *out_pos, unsigned *out_cnt, hipStream_t s, const DeviceInfo &dev) {
   const JlLayout L = jl_layout(n_build);
-  const u32x4 *table = reinterpret_cast<const u32x4 *>(static_cast<const char *>(workspace) + L.table_off);
+  const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
   hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
                      table, L.parts, out_pos, out_cnt);
   return launch_status();
