@@ -65,9 +65,15 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__
   if (lo >= hi) return;
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_hist[i] = 0;
   __syncthreads();
-  for (size_t i = lo + static_cast<size_t>(w) * kJlThreads + threadIdx.x; i < hi;
-       i += static_cast<size_t>(kJlHistWgPerGroup) * kJlThreads)
-    atomicAdd(&s_hist[jl_pid(keys[i], parts) >> k2_shift], 1u);
+  for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlThreads + threadIdx.x; i < hi;
+       i += static_cast<size_t>(kJlHistWgPerGroup) * 4 * kJlThreads) {  // four independent loads per lane per step
+    unsigned k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlThreads < hi ? keys[i + j * kJlThreads] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts) >> k2_shift], 1u);
+  }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
     if (s_hist[i]) atomicAdd(&counts_g[static_cast<size_t>(group) * k1 + i], static_cast<unsigned long long>(s_hist[i]));
@@ -260,20 +266,29 @@ __device__ __forceinline__ bool jl_locate(const unsigned long long *__restrict__
   return true;
 }
 
+// level-1 histogram: kJlHist1WgPerBucket workgroups stride over one level-0 bucket (four independent loads per
+// lane per step), so a bucket's k2 counters see 16 flushes instead of one per 4096-row tile
+constexpr unsigned kJlHist1WgPerBucket = 16;
+
 __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__restrict__ keys,
                                                               const unsigned long long *__restrict__ starts0,
-                                                              const unsigned long long *__restrict__ tile_starts,
-                                                              unsigned parts, unsigned k1, unsigned k2,
+                                                              unsigned parts, unsigned k2,
                                                               unsigned long long *counts1) {
   extern __shared__ unsigned s_hist[];
-  unsigned bucket;
-  unsigned long long tile;
-  if (!jl_locate(tile_starts, k1, blockIdx.x, &bucket, &tile)) return;
+  const unsigned bucket = blockIdx.x / kJlHist1WgPerBucket, w = blockIdx.x % kJlHist1WgPerBucket;
+  const size_t lo = starts0[bucket], hi = starts0[bucket + 1];
+  if (lo + static_cast<size_t>(w) * 4 * kJlThreads >= hi) return;
   for (unsigned i = threadIdx.x; i < k2; i += kJlThreads) s_hist[i] = 0;
   __syncthreads();
-  const size_t lo = starts0[bucket] + tile * kJlTile;
-  const size_t hi = lo + kJlTile < starts0[bucket + 1] ? lo + kJlTile : starts0[bucket + 1];
-  for (size_t i = lo + threadIdx.x; i < hi; i += kJlThreads) atomicAdd(&s_hist[jl_pid(keys[i], parts) & (k2 - 1)], 1u);
+  for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlThreads + threadIdx.x; i < hi;
+       i += static_cast<size_t>(kJlHist1WgPerBucket) * 4 * kJlThreads) {
+    unsigned k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlThreads < hi ? keys[i + j * kJlThreads] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts) & (k2 - 1)], 1u);
+  }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
     if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
@@ -457,8 +472,8 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   if (L.k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
     const size_t lds1 = jl_scatter_lds_bytes(L.k2);
-    hipLaunchKernelGGL(jl_hist1_kernel, dim3(vtiles), dim3(kJlThreads), L.k2 * sizeof(unsigned), s, k_a, starts0,
-                       tstarts0, L.parts, L.k1, L.k2, counts1);
+    hipLaunchKernelGGL(jl_hist1_kernel, dim3(L.k1 * kJlHist1WgPerBucket), dim3(kJlThreads), L.k2 * sizeof(unsigned), s,
+                       k_a, starts0, L.parts, L.k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(L.k1), dim3(kJlThreads), 0, s, counts1, starts0, L.k1, L.k2, starts1,
                        cursors1);
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
