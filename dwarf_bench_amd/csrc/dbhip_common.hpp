@@ -36,6 +36,13 @@ inline bool ws_ok(const void *ws, size_t have, size_t need) {
 }
 inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 
+// Fill `bytes` (a multiple of 4, `p` 4-byte aligned) with the byte `value`, asynchronously, by a kernel of this
+// library (dbhip_util.hip).  Used instead of hipMemsetAsync everywhere: a captured hipMemsetAsync becomes a graph
+// memset node, and replaying those left pointer-like garbage in the workspace header on ROCm 7.2
+// (tests/test_gpu_graph.py); a plain kernel node replays correctly, and costs 2 us instead of the 4.5 us of
+// __amd_rocclr_fillBufferAligned.
+hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s);
+
 // Blocks per CU a PERSISTENT grid may count on being co-resident (look-back kernels wait on lower
 // tiles, so the grid must never exceed residency).  `want` is capped at 5: ROCm 7.2's occupancy API
 // over-reports by one block per CU only where SGPR use limits a 256-thread kernel to 6-7 blocks

@@ -30,6 +30,20 @@ const DeviceInfo &current_device_info() {
 
 namespace {
 
+constexpr int kFillThreads = 256;
+
+// words [0, head) and [head + 4*vecs, words) one by one, the 16-byte aligned middle as u32x4 stores
+__global__ __launch_bounds__(kFillThreads) void fill_kernel(unsigned *p, unsigned v, size_t words, size_t head,
+                                                             size_t vecs) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kFillThreads;
+  const size_t t = static_cast<size_t>(blockIdx.x) * kFillThreads + threadIdx.x;
+  u32x4 *mid = reinterpret_cast<u32x4 *>(p + head);
+  for (size_t i = t; i < vecs; i += stride) mid[i] = u32x4{v, v, v, v};
+  const size_t tail0 = head + 4 * vecs;
+  for (size_t i = t; i < head; i += stride) p[i] = v;
+  for (size_t i = tail0 + t; i < words; i += stride) p[i] = v;
+}
+
 constexpr int kGenThreads = 256;
 
 __global__ __launch_bounds__(kGenThreads) void gen_uniform_u32_kernel(uint32_t *out, size_t n,
@@ -57,6 +71,25 @@ inline unsigned gen_grid(size_t n) {
 }
 
 }  // namespace
+
+hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (!p || (a & 3u) || (bytes & 3u)) return hipErrorInvalidValue;
+  const size_t words = bytes / 4;
+  size_t head = ((16 - (a & 15u)) & 15u) / 4;
+  if (head > words) head = words;
+  const size_t vecs = (words - head) / 4;
+  const unsigned b = static_cast<unsigned>(value) & 0xFFu;
+  const size_t want = (vecs + kFillThreads - 1) / kFillThreads;
+  const DeviceInfo &d = current_device_info();
+  const size_t cap = static_cast<size_t>(d.ok ? d.cus : 256) * 8;
+  const unsigned grid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(kFillThreads), 0, s, static_cast<unsigned *>(p), b * 0x01010101u,
+                     words, head, vecs);
+  return hipGetLastError();
+}
+
 }  // namespace dbhip
 
 using namespace dbhip;

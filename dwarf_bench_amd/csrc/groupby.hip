@@ -195,7 +195,7 @@ int gb_partial(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t gr
   const size_t partial_words = static_cast<size_t>(geo.ranges) * geo.chunk_slots * geo.range_groups;
   if (!ws_ok(workspace, workspace_bytes, kWsHeader + partial_words * sizeof(unsigned))) return DBHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(workspace, 0, kWsHeader, s);
+  hipError_t e = fill_async(workspace, 0, kWsHeader, s);
   if (e != hipSuccess) return static_cast<int>(e);
   GbHeader *hdr = static_cast<GbHeader *>(workspace);
   unsigned *partials = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + kWsHeader);

@@ -272,13 +272,10 @@ int join_build_impl(const uint32_t *build_keys, const uint32_t *row_ids, size_t 
   unsigned long long *gran = reinterpret_cast<unsigned long long *>(base + L.gran_off);
   const unsigned mask = static_cast<unsigned>(L.cap - 1);
 
-  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = hipMemsetAsync(keys, 0xFF, L.cap * sizeof(unsigned), s);
-  if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, L.cap * sizeof(unsigned), s);
-  if (e == hipSuccess) e = hipMemsetAsync(gran, 0, L.total - L.gran_off, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const unsigned long long hdr_vals[2] = {L.cap, n_build};
-  e = hipMemcpyAsync(&hdr->capacity, hdr_vals, sizeof(hdr_vals), hipMemcpyHostToDevice, s);
+  hipError_t e = fill_async(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = fill_async(keys, 0xFF, L.cap * sizeof(unsigned), s);
+  if (e == hipSuccess) e = fill_async(cnt, 0, L.cap * sizeof(unsigned), s);
+  if (e == hipSuccess) e = fill_async(gran, 0, L.total - L.gran_off, s);
   if (e != hipSuccess) return static_cast<int>(e);
 
   if (n_build)
@@ -346,11 +343,8 @@ extern "C" int dbhip_ujoin_build_u32(const uint32_t *build_keys, const uint32_t 
   UjoinHeader *hdr = reinterpret_cast<UjoinHeader *>(base);
   unsigned *keys = reinterpret_cast<unsigned *>(base + kWsHeader);
   unsigned *vals = keys + cap;
-  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = hipMemsetAsync(keys, 0xFF, cap * sizeof(unsigned), s);
-  const unsigned long long capv = cap;
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(&hdr->capacity, &capv, sizeof(capv), hipMemcpyHostToDevice, s);
+  hipError_t e = fill_async(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = fill_async(keys, 0xFF, cap * sizeof(unsigned), s);
   if (e != hipSuccess) return static_cast<int>(e);
   if (n_build)
     hipLaunchKernelGGL(ujoin_build_kernel, dim3(grid_for(n_build, dev, 8)), dim3(kJoinThreads), 0, s,
@@ -517,10 +511,10 @@ extern "C" int dbhip_bitmask_table_reset(void *workspace, size_t workspace_bytes
   if (!ws_ok(workspace, workspace_bytes, L.total)) return DBHIP_EWORKSPACE;
   char *base = static_cast<char *>(workspace);
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = hipMemsetAsync(base + L.keys_off, 0xFF, table_size * sizeof(unsigned), s);  // join.cpp:37
-  if (e == hipSuccess) e = hipMemsetAsync(base + L.vals_off, 0, table_size * sizeof(unsigned), s);
-  if (e == hipSuccess) e = hipMemsetAsync(base + L.mask_off, 0, L.mask_words * sizeof(unsigned), s);
+  hipError_t e = fill_async(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = fill_async(base + L.keys_off, 0xFF, table_size * sizeof(unsigned), s);  // join.cpp:37
+  if (e == hipSuccess) e = fill_async(base + L.vals_off, 0, table_size * sizeof(unsigned), s);
+  if (e == hipSuccess) e = fill_async(base + L.mask_off, 0, L.mask_words * sizeof(unsigned), s);
   return static_cast<int>(e);
 }
 

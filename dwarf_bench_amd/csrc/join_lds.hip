@@ -451,8 +451,8 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   unsigned long long *starts1 = counts1 + L.parts;
   unsigned long long *cursors1 = starts1 + L.parts + 1;
 
-  hipError_t e = hipMemsetAsync(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = hipMemsetAsync(meta, 0, L.meta_bytes, s);
+  hipError_t e = fill_async(base, 0, kWsHeader, s);
+  if (e == hipSuccess) e = fill_async(meta, 0, L.meta_bytes, s);
   if (e != hipSuccess) return static_cast<int>(e);
 
   const unsigned k2_shift = L.log2_k2;
@@ -516,7 +516,7 @@ int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, u
   unsigned long long *cursors0 = counts0 + static_cast<size_t>(kJlGroups) * parts;
   unsigned long long *starts0 = cursors0 + static_cast<size_t>(kJlGroups) * parts;
   unsigned long long *tstarts0 = starts0 + parts + 1;
-  hipError_t e = hipMemsetAsync(base, 0, jl_partition_workspace_bytes(parts), s);
+  hipError_t e = fill_async(base, 0, jl_partition_workspace_bytes(parts), s);
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), parts * sizeof(unsigned), s,
                      keys, n, parts, 0u, parts, counts0);

@@ -355,7 +355,7 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
   unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
 
-  hipError_t e = hipMemsetAsync(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
+  hipError_t e = fill_async(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
   if (e != hipSuccess) return static_cast<int>(e);
 
   const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;

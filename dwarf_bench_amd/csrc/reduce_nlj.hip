@@ -87,7 +87,7 @@ extern "C" int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, 
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), s);
+  hipError_t e = fill_async(out, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return static_cast<int>(e);
   if (n == 0) return DBHIP_OK;
   const size_t tiles = (n + kRedTileInts - 1) / kRedTileInts;

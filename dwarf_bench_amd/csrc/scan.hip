@@ -323,7 +323,7 @@ int launch_chunked(const int *src, size_t n, int filter, int *out, unsigned long
   ScanWs *ws = reinterpret_cast<ScanWs *>(base);
   unsigned *counts = reinterpret_cast<unsigned *>(base + L.counts_off);
   int *staging = reinterpret_cast<int *>(base + L.staging_off);
-  hipError_t e = hipMemsetAsync(workspace, 0, kWsHeader, s);  // status word + ticket counter
+  hipError_t e = fill_async(workspace, 0, kWsHeader, s);  // status word + ticket counter
   if (e != hipSuccess) return static_cast<int>(e);
   const size_t cap = static_cast<size_t>(dev.cus);  // one 16-wave workgroup per CU
   const unsigned grid = static_cast<unsigned>(L.chunks < cap ? L.chunks : cap);
@@ -358,8 +358,8 @@ extern "C" int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
   if (n == 0) {
-    hipError_t e = hipMemsetAsync(workspace, 0, kWsHeader, s);
-    if (e == hipSuccess) e = hipMemsetAsync(out_size, 0, sizeof(uint64_t), s);
+    hipError_t e = fill_async(workspace, 0, kWsHeader, s);
+    if (e == hipSuccess) e = fill_async(out_size, 0, sizeof(uint64_t), s);
     return static_cast<int>(e);
   }
   unsigned long long *osz = reinterpret_cast<unsigned long long *>(out_size);
@@ -372,7 +372,7 @@ extern "C" int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter
   }
   const size_t tiles = (n + kScanSmallTile - 1) / kScanSmallTile;
   // ticket counter, status word and granules must be zero before every launch
-  hipError_t e = hipMemsetAsync(workspace, 0, align_up(kWsHeader + tiles * sizeof(unsigned long long), 16), s);
+  hipError_t e = fill_async(workspace, 0, align_up(kWsHeader + tiles * sizeof(unsigned long long), 16), s);
   if (e != hipSuccess) return static_cast<int>(e);
   ScanWs *ws = static_cast<ScanWs *>(workspace);
   if (!aligned) return launch_small<false, false>(src, n, filter_value, out, osz, ws, dev, tiles, s);
