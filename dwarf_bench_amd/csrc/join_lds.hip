@@ -39,6 +39,16 @@ constexpr int kJlBuildThreads = 512;
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
   return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key)) * parts) >> 32);
 }
+// Destination RANK of the multi-GPU partitioner: a second, independent hash.  It must not be the high bits of
+// fmix32(key) again: a rank only receives keys of one rank bucket, and its local build (jl_pid above) would then
+// find all of them in 1/P of its partitions — P times overfull sub-tables (TABLE_FULL at P = 8).
+__device__ __forceinline__ unsigned jl_rank_of(unsigned key, unsigned parts) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key * 0x9E3779B1u + 0x7F4A7C15u)) * parts) >> 32);
+}
+template <bool RANK>
+__device__ __forceinline__ unsigned jl_pid_sel(unsigned key, unsigned parts) {
+  return RANK ? jl_rank_of(key, parts) : jl_pid(key, parts);
+}
 
 // ---- level 0: histogram per (tile group, bucket) --------------------------------------------------
 // The column's 4096-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
@@ -53,6 +63,7 @@ __device__ __forceinline__ size_t jl_tiles_per_group(size_t n) {
   return (tiles + kJlGroups - 1) / kJlGroups;
 }
 
+template <bool RANK>
 __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__restrict__ keys, size_t n,
                                                               unsigned parts, unsigned k2_shift,
                                                               unsigned k1, unsigned long long *counts_g) {
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__
     for (int j = 0; j < 4; ++j) k[j] = i + j * kJlThreads < hi ? keys[i + j * kJlThreads] : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts) >> k2_shift], 1u);
+      if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid_sel<RANK>(k[j], parts) >> k2_shift], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads)
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned 
 constexpr size_t jl_scatter_lds_bytes(unsigned nb) {
   return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + 16;
 }
-template <int LEVEL>
+template <int LEVEL, bool RANK = false>
 __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], const unsigned (&rid)[kJlKpt],
                                                 const unsigned (&dest)[kJlKpt], unsigned nb, unsigned parts,
                                                 unsigned arg, unsigned long long *cursors,
@@ -217,7 +228,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   __syncthreads();
   for (unsigned p = tid; p < total; p += kJlThreads) {
     const unsigned k = s_keys[p];
-    const unsigned pid = jl_pid(k, parts);
+    const unsigned pid = jl_pid_sel<RANK>(k, parts);
     const unsigned d = LEVEL == 0 ? pid >> arg : pid & arg;
     const size_t slot = s_base[d] + (p - s_excl[d]);
     out_keys[slot] = k;
@@ -227,6 +238,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
 }
 
 // level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
+template <bool RANK>
 __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ row_ids,
                                                                  unsigned long long first_row, size_t n,
@@ -245,10 +257,10 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
       const bool valid = idx < n;
       key[j] = valid ? keys[idx] : 0u;
       rid[j] = valid ? (row_ids ? row_ids[idx] : static_cast<unsigned>(first_row + idx)) : 0u;
-      dest[j] = valid ? jl_pid(key[j], parts) >> k2_shift : k1;
+      dest[j] = valid ? jl_pid_sel<RANK>(key[j], parts) >> k2_shift : k1;
     }
     const size_t group = tile / jl_tiles_per_group(n);  // this tile bumps only its group's cursors
-    jl_scatter_tile<0>(key, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem);
+    jl_scatter_tile<0, RANK>(key, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem);
   }
 }
 
@@ -457,14 +469,14 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
 
   const unsigned k2_shift = L.log2_k2;
   const size_t lds0 = jl_scatter_lds_bytes(L.k1);
-  hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), L.k1 * sizeof(unsigned),
-                     s, build_keys, n, L.parts, k2_shift, L.k1, counts0);
+  hipLaunchKernelGGL(jl_hist0_kernel<false>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
+                     L.k1 * sizeof(unsigned), s, build_keys, n, L.parts, k2_shift, L.k1, counts0);
   hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, cursors0, starts0, tstarts0,
                      static_cast<unsigned long long *>(nullptr));
   {
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
-    hipLaunchKernelGGL(jl_scatter0_kernel, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
+    hipLaunchKernelGGL(jl_scatter0_kernel<false>, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
                        lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
   }
   const unsigned *pk = k_a, *pr = r_a;
@@ -518,14 +530,14 @@ int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, u
   unsigned long long *tstarts0 = starts0 + parts + 1;
   hipError_t e = fill_async(base, 0, jl_partition_workspace_bytes(parts), s);
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(jl_hist0_kernel, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads), parts * sizeof(unsigned), s,
-                     keys, n, parts, 0u, parts, counts0);
+  hipLaunchKernelGGL(jl_hist0_kernel<true>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
+                     parts * sizeof(unsigned), s, keys, n, parts, 0u, parts, counts0);
   hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, parts, cursors0, starts0, tstarts0,
                      out_counts);
   if (n) {
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
-    hipLaunchKernelGGL(jl_scatter0_kernel, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
+    hipLaunchKernelGGL(jl_scatter0_kernel<true>, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
                        jl_scatter_lds_bytes(parts), s, keys, static_cast<const unsigned *>(nullptr), first_row, n, parts,
                        0u, parts, cursors0, out_keys, out_rids);
   }

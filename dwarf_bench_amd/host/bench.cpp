@@ -56,6 +56,7 @@ std::vector<Measurement> DwarfBench::makeMeasurements(const RunConfig &conf) {
   base.input_size = {conf.inputSize};
   base.iterations = conf.iterations;
   base.report_path = "";
+  base.devices = conf.devices;
   GroupByRunOptions opts(base, conf.groups_count, conf.executors);
 
   const DwarfImpl impl = dwarfToImpl(conf.dwarf);

@@ -42,6 +42,7 @@ struct RunConfig {
   Dwarf dwarf;
   size_t groups_count = 20;  // GroupBy only
   size_t executors = 1024;   // GroupByLocal-style dwarfs only
+  size_t devices = 1;        // GPUs for multi-GPU dwarfs (PartitionedJoinHip)
 };
 
 class DwarfBench {

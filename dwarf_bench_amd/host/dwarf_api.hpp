@@ -29,6 +29,7 @@ struct RunOptions {
   size_t iterations = 1;
   std::string root_path;
   std::string report_path;
+  size_t devices = 1;  // additive (no reference counterpart): GPUs a multi-GPU dwarf spreads over, CLI --gpus
 };
 
 struct GroupByRunOptions : public RunOptions {

@@ -27,6 +27,7 @@ DBHIP_DECLARE_DWARF(RadixHip);
 DBHIP_DECLARE_DWARF(GroupByHip);
 DBHIP_DECLARE_DWARF(JoinOmnisciHip);
 DBHIP_DECLARE_DWARF(JoinHip);
+DBHIP_DECLARE_DWARF(PartitionedJoinHip);      // radix-partitioned join over --gpus ranks, RCCL exchange
 // SURVEY 8(f) "next" rows
 DBHIP_DECLARE_DWARF(GroupByLocalHip);         // groupby/groupby_local.cpp:24-142 (two-phase timings, --executors)
 DBHIP_DECLARE_DWARF(HashBuildHip);            // hash/hash_build.cpp:8-98 (bitmask-claimed table, build only)

@@ -1,7 +1,7 @@
 // main.cpp — the `dwarf_bench` CLI (reference: main.cpp:13-101) with the same positional argument and
 // flags, parsed by hand (Boost.program_options is not available here):
 //   dwarf_bench <Dwarf|list> [--input_size N [N ...]] [--iterations K] [--device cpu|gpu|igpu|hip]
-//               [--report_path FILE] [--groups_count G] [--executors E] [--help]
+//               [--report_path FILE] [--groups_count G] [--executors E] [--gpus P] [--help]
 // Exit codes as in the reference: 1 for an unknown dwarf, 0 otherwise — also after a caught exception.
 #include <iostream>
 #include <memory>
@@ -24,7 +24,8 @@ const char *kHelp =
     "  --device arg           Device to run on.\n"
     "  --report_path arg      Full/Relative path to a report file.\n"
     "  --groups_count arg     Number of unique keys for dwarfs with keys (groupby, hash build etc.).\n"
-    "  --executors arg        Number of executors for GroupByLocal.\n";
+    "  --executors arg        Number of executors for GroupByLocal.\n"
+    "  --gpus arg             Number of GPUs (ranks) for PartitionedJoinHip (default 1).\n";
 
 bool is_flag(const std::string &s) { return s.rfind("--", 0) == 0; }
 }  // namespace
@@ -73,6 +74,8 @@ int main(int argc, char *argv[]) {
         groups_count = std::stoull(next_value());
       } else if (arg == "--executors") {
         executors = std::stoull(next_value());
+      } else if (arg == "--gpus") {
+        opts->devices = std::stoull(next_value());
       } else if (!is_flag(arg) && dwarf_name.empty()) {
         dwarf_name = arg;  // positional: the dwarf
       } else {

@@ -13,6 +13,7 @@ void populate_registry() {
   registry->registerd(new GroupByHip());
   registry->registerd(new JoinOmnisciHip());
   registry->registerd(new JoinHip());
+  registry->registerd(new PartitionedJoinHip());
   registry->registerd(new GroupByLocalHip());
   registry->registerd(new HashBuildHip());
   registry->registerd(new HashBuildNonBitmaskHip());

@@ -17,8 +17,10 @@ def fmix32(k: np.ndarray) -> np.ndarray:
 
 
 def dest_of(keys: np.ndarray, parts: int) -> np.ndarray:
-    """(fmix32(key) * parts) >> 32, as pj_dest in csrc/pjoin.hip"""
-    return ((fmix32(keys) * np.uint64(parts)) >> np.uint64(32)).astype(np.int64)
+    """(fmix32(key * 0x9E3779B1 + 0x7F4A7C15) * parts) >> 32, as jl_rank_of in csrc/join_lds.hip: a hash independent
+    of the one the local join partitions by"""
+    pre = (keys.astype(np.uint64) * np.uint64(0x9E3779B1) + np.uint64(0x7F4A7C15)) & np.uint64(0xFFFFFFFF)
+    return ((fmix32(pre) * np.uint64(parts)) >> np.uint64(32)).astype(np.int64)
 
 
 class OracleBackend:

@@ -50,6 +50,23 @@ def test_groupby_local_suite(tmp_path, executors):
         assert row[0] == "HIP" and gb > 0 and red >= 0 and abs(total - (gb + red)) <= 0.0025  # whole-us truncation
 
 
+@pytest.mark.parametrize("gpus,env", [("1", {}), ("1", {"DWARF_BENCH_PJOIN_EXCHANGE": "copy"}), ("2", {}), ("3", {}),
+                                      ("8", {})])
+def test_partitioned_join_dwarf(gpus, env):
+    """PartitionedJoinHip through the CLI.  One GPU on the test box: --gpus 1 runs the RCCL send/recv
+    group against itself (or the peer-copy exchange when forced), more ranks than GPUs share the device and
+    exchange by hipMemcpyPeerAsync.  Sizes include ragged shards (n % P != 0) and n < P."""
+    import os
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "3", "--input_size", "5", "1000",
+              "65536", "300007", "2097152"], env={**os.environ, **env})
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Build time:") == 3 * 5 and r.stdout.count("Exchange time:") == 3 * 5
+    assert f"{gpus} rank(s) on 1 GPU(s)" in r.stdout
+    want = "RCCL" if (gpus == "1" and not env) else "hipMemcpyPeerAsync"
+    assert f"exchange by {want}" in r.stdout
+
+
 def test_baseline_plumbing_config_csv(tmp_path):
     """BASELINE configs[0] on the HIP device: TwoPassScan --input_size=1024 --iterations=9 -> 9 valid rows,
     reference CSV schema (common/result.cpp:59-91), appended on a second run."""

@@ -52,6 +52,28 @@ def test_bucket_balance_on_uniform_keys():
     assert c.sum() == n and c.max() / c.mean() < 1.01
 
 
+@pytest.mark.parametrize("parts", [2, 8])
+def test_rank_hash_is_independent_of_the_local_partition_hash(parts):
+    """A rank joins only keys of ONE rank bucket.  If the rank hash were the same high hash bits the local build
+    partitions by, those keys would fill 1/parts of its LDS sub-tables parts-fold (TABLE_FULL at 8 ranks)."""
+    from dwarf_bench_amd import ops
+    n = 1 << 22
+    keys = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    ok, orid, cnt = ops.partition_by_hash(keys, 0, parts)
+    c = cnt.cpu().numpy()
+    for b in (0, parts - 1):
+        lo = int(c[:b].sum())
+        mine = ok[lo: lo + int(c[b])].contiguous()
+        rids = orid[lo: lo + int(c[b])].contiguous()
+        assert mine.numel() >= 1 << 16  # the LDS-partitioned build path
+        plan = ops.HashJoin(mine.numel(), mine.numel())
+        plan.build(mine, rids)
+        plan.probe(mine)
+        pos, cnt_out, ids = plan.result()  # raises on TABLE_FULL
+        h = mine.cpu().numpy().view(np.uint32)
+        assert np.array_equal(cnt_out.cpu().numpy().view(np.uint32), po.join_counts_fast(h, h).astype(np.uint32))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
