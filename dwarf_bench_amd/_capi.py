@@ -4,9 +4,12 @@ import of the product path fails loudly."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libdbhip.so"
+if os.environ.get("DBHIP_LIB"):  # kernel experiments: an alternative build of the same library
+    _LIB_PATH = Path(os.environ["DBHIP_LIB"])
 
 c_u32p = C.POINTER(C.c_uint32)
 _vp, _sz, _u64, _u32, _i32, _int = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int32, C.c_int

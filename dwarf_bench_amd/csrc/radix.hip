@@ -33,7 +33,16 @@ namespace {
 
 constexpr int kRsThreads = 256;
 constexpr int kRsWaves = kRsThreads / kWave;
-constexpr int kRsKpt = 16;                       // keys per lane per tile
+// Tile shape of the scatter kernel (compile-time knobs for experiments).  Measured at 2^24 full-range keys, 8-bit:
+// 16 keys/lane at 4 waves/SIMD (128 VGPRs) 356 us; 8 keys/lane at 6 waves/SIMD (80 VGPRs) 379 us; 8 at 8 (spills)
+// 443 us; 16 at 5 (spills) 553 us — more resident waves do not help, wider tiles do.
+#ifndef DBHIP_RS_KPT
+#define DBHIP_RS_KPT 16
+#endif
+#ifndef DBHIP_RS_WPE
+#define DBHIP_RS_WPE 4
+#endif
+constexpr int kRsKpt = DBHIP_RS_KPT;             // keys per lane per tile
 constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 4096 keys
 constexpr int kRsMaxPasses = 8;
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
 
 // ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
 template <int BITS>
-__global__ __launch_bounds__(kRsThreads, 4) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
+__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
                                                                          int pass, unsigned xor_mask,
                                                                          const RsHeader *hdr,
                                                                          const unsigned *__restrict__ offsets,
