@@ -327,6 +327,7 @@ extern "C" int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, 
 }
 
 extern "C" size_t dbhip_ujoin_workspace_bytes(size_t n_build) {
+  if (jl_use(n_build)) return jl_layout(n_build).total;  // radix-partitioned build, LDS sub-tables (join_lds.hip)
   return align_up(kWsHeader + 2 * join_capacity(n_build) * sizeof(unsigned), kWsAlign);
 }
 
@@ -338,6 +339,7 @@ extern "C" int dbhip_ujoin_build_u32(const uint32_t *build_keys, const uint32_t 
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
+  if (jl_use(n_build)) return ujoin_lds_build(build_keys, build_vals, n_build, workspace, s, dev);
   const size_t cap = join_capacity(n_build);
   char *base = static_cast<char *>(workspace);
   UjoinHeader *hdr = reinterpret_cast<UjoinHeader *>(base);
@@ -361,6 +363,9 @@ extern "C" int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t 
     return DBHIP_EINVAL;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
+  if (jl_use(n_build))
+    return ujoin_lds_probe(probe_keys, probe_vals, n_probe, workspace, n_build, out_key, out_build_val, out_probe_val,
+                           as_stream(stream), dev);
   const size_t cap = join_capacity(n_build);
   const char *base = static_cast<const char *>(workspace);
   const unsigned *keys = reinterpret_cast<const unsigned *>(base + kWsHeader);

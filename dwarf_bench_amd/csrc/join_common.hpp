@@ -58,6 +58,11 @@ size_t jl_partition_workspace_bytes(unsigned parts);
 int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, unsigned parts, unsigned *out_keys,
                  unsigned *out_rids, unsigned long long *out_counts, void *workspace, hipStream_t s,
                  const DeviceInfo &dev);
+int ujoin_lds_build(const unsigned *build_keys, const unsigned *build_vals, size_t n, void *workspace, hipStream_t s,
+                    const DeviceInfo &dev);
+int ujoin_lds_probe(const unsigned *probe_keys, const unsigned *probe_vals, size_t n_probe, const void *workspace,
+                    size_t n_build, unsigned *out_key, unsigned *out_bval, unsigned *out_pval, hipStream_t s,
+                    const DeviceInfo &dev);
 int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *workspace, size_t n_build,
                    unsigned *out_pos, unsigned *out_cnt, hipStream_t s, const DeviceInfo &dev);
 

@@ -434,6 +434,76 @@ __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__
   }
 }
 
+// ---- unique-key payload join (dwarf 4b, join/join.cpp:60-131) over the same partitions -----------------------
+// One workgroup per partition: ds_cmpst claims the key's slot, the claimer stores its payload next to it (a
+// duplicate build key keeps the first claimer's payload: keys are unique by contract, join/join.cpp:13-16), the
+// sub-table goes out as 8-byte slots {key, payload}.  Probe: one 8-byte gather per step.
+__global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsigned *__restrict__ pkeys,
+                                                                    const unsigned *__restrict__ pvals,
+                                                                    const unsigned long long *__restrict__ starts,
+                                                                    u32x2 *__restrict__ table, unsigned *status) {
+  __shared__ unsigned lk[kJlSubSlots];
+  __shared__ unsigned lv[kJlSubSlots];
+  const unsigned tid = threadIdx.x;
+  const size_t part = blockIdx.x;
+  const size_t lo = starts[part], hi = starts[part + 1];
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
+    lk[i] = kEmptyKey;
+    lv[i] = kEmptyKey;
+  }
+  __syncthreads();
+  for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
+    const unsigned key = pkeys[i];
+    unsigned s = fmix32(key) & kJlSubMask;
+    for (unsigned tries = 0;; ++tries) {
+      const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
+      if (old == kEmptyKey) {
+        lv[s] = pvals[i];
+        break;
+      }
+      if (old == key) break;
+      s = (s + 1) & kJlSubMask;
+      if (tries >= kJlSubMask) {
+        atomicOr(status, DBHIP_DEV_TABLE_FULL);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  u32x2 *dst = table + part * kJlSubSlots;
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) dst[i] = u32x2{lk[i], lv[i]};
+}
+
+__global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *__restrict__ pkeys,
+                                                               const unsigned *__restrict__ pvals, size_t n,
+                                                               const u32x2 *__restrict__ table, unsigned parts,
+                                                               unsigned *__restrict__ out_key,
+                                                               unsigned *__restrict__ out_bval,
+                                                               unsigned *__restrict__ out_pval) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned key = pkeys[i];
+    const unsigned h = fmix32(key);
+    const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+    unsigned s = h & kJlSubMask, bval = kEmptyKey;
+    bool found = false;
+    for (unsigned tries = 0; tries <= kJlSubMask; ++tries) {
+      const u32x2 e = sub[s];
+      if (e.x == key) {
+        found = true;
+        bval = e.y;
+        break;
+      }
+      if (e.x == kEmptyKey) break;
+      s = (s + 1) & kJlSubMask;
+    }
+    // join.cpp:41-43, :96-101: sentinels where the probe row has no partner
+    out_key[i] = found ? key : kEmptyKey;
+    out_bval[i] = bval;
+    out_pval[i] = found ? pvals[i] : kEmptyKey;
+  }
+}
+
 inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
   const size_t want = (items + kJlThreads - 1) / kJlThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
@@ -442,13 +512,18 @@ inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
 
 }  // namespace
 
-// ---- host side (called from join.hip's entry points) ---------------------------------------------------
-int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n, unsigned *ids, void *workspace,
-                   hipStream_t s, const DeviceInfo &dev) {
-  const JlLayout L = jl_layout(n);
+namespace {
+struct JlPartitioned {
+  const unsigned *keys, *rids;             // partition-major (key, row id / payload) pairs
+  const unsigned long long *starts;        // parts + 1 offsets
+  u32x2 *table;
+  unsigned *status;
+};
+
+// the one or two scatter levels shared by both joins: fills `out` and returns a HIP/dbhip status
+int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_t n, void *workspace, hipStream_t s,
+                      const DeviceInfo &dev, const JlLayout &L, JlPartitioned *out) {
   char *base = static_cast<char *>(workspace);
-  unsigned *status = reinterpret_cast<unsigned *>(base);
-  u32x2 *table = reinterpret_cast<u32x2 *>(base + L.table_off);
   unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);
   unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);
   unsigned *k_b = reinterpret_cast<unsigned *>(base + L.keys_b_off);
@@ -479,8 +554,9 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
     hipLaunchKernelGGL(jl_scatter0_kernel<false>, dim3(static_cast<unsigned>(tiles < cap ? tiles : cap)), dim3(kJlThreads),
                        lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
   }
-  const unsigned *pk = k_a, *pr = r_a;
-  const unsigned long long *pstarts = starts0;
+  out->keys = k_a;
+  out->rids = r_a;
+  out->starts = starts0;
   if (L.k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
     const size_t lds1 = jl_scatter_lds_bytes(L.k2);
@@ -490,17 +566,51 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
                        cursors1);
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
                        L.parts, L.k1, L.k2, cursors1, k_b, r_b);
-    pk = k_b;
-    pr = r_b;
-    pstarts = starts1;
+    out->keys = k_b;
+    out->rids = r_b;
+    out->starts = starts1;
   }
+  out->table = reinterpret_cast<u32x2 *>(base + L.table_off);
+  out->status = reinterpret_cast<unsigned *>(base);
+  return launch_status();
+}
+}  // namespace
+
+// ---- host side (called from join.hip's entry points) ---------------------------------------------------
+int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n, unsigned *ids, void *workspace,
+                   hipStream_t s, const DeviceInfo &dev) {
+  const JlLayout L = jl_layout(n);
+  JlPartitioned p;
+  const int rc = jl_partition_rows(build_keys, row_ids, n, workspace, s, dev, L, &p);
+  if (rc != 0) return rc;
   const size_t build_lds = 3 * kJlSubSlots * sizeof(unsigned);
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, pk, pr, pstarts, table, L.parts,
-                     static_cast<unsigned>(n), ids,
-                     status);
+  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, p.keys, p.rids, p.starts,
+                     p.table, L.parts, static_cast<unsigned>(n), ids, p.status);
+  return launch_status();
+}
+
+// unique-key payload join: `build_vals` ride through the partition in the row-id column
+int ujoin_lds_build(const unsigned *build_keys, const unsigned *build_vals, size_t n, void *workspace, hipStream_t s,
+                    const DeviceInfo &dev) {
+  const JlLayout L = jl_layout(n);
+  JlPartitioned p;
+  const int rc = jl_partition_rows(build_keys, build_vals, n, workspace, s, dev, L, &p);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(jl_ubuild_kernel, dim3(L.parts), dim3(kJlBuildThreads), 0, s, p.keys, p.rids, p.starts, p.table,
+                     p.status);
+  return launch_status();
+}
+
+int ujoin_lds_probe(const unsigned *probe_keys, const unsigned *probe_vals, size_t n_probe, const void *workspace,
+                    size_t n_build, unsigned *out_key, unsigned *out_bval, unsigned *out_pval, hipStream_t s,
+                    const DeviceInfo &dev) {
+  const JlLayout L = jl_layout(n_build);
+  const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
+  hipLaunchKernelGGL(jl_uprobe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, probe_vals,
+                     n_probe, table, L.parts, out_key, out_bval, out_pval);
   return launch_status();
 }
 

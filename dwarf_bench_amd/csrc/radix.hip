@@ -35,7 +35,7 @@ constexpr int kRsThreads = 256;
 constexpr int kRsWaves = kRsThreads / kWave;
 // Tile shape of the scatter kernel (compile-time knobs for experiments).  Measured at 2^24 full-range keys, 8-bit:
 // 16 keys/lane at 4 waves/SIMD (128 VGPRs) 356 us; 8 keys/lane at 6 waves/SIMD (80 VGPRs) 379 us; 8 at 8 (spills)
-// 443 us; 16 at 5 (spills) 553 us — more resident waves do not help, wider tiles do.
+// 443 us; 16 at 5 (spills) 553 us — more resident waves with narrower tiles do not pay.
 #ifndef DBHIP_RS_KPT
 #define DBHIP_RS_KPT 16
 #endif

@@ -110,3 +110,41 @@ def test_ujoin_reference_fixture_shape(golden_dir):
             sk, s1, s2 = po.seq_join(ak, av, bk, bv)
             assert sorted(zip(ok[hit].tolist(), o1[hit].tolist(), o2[hit].tolist())) == \
                 sorted(zip(sk.tolist(), s1.tolist(), s2.tolist()))
+
+
+@pytest.mark.parametrize("n", [1 << 16, 100003, 1 << 20, (1 << 22) + 77])
+def test_ujoin_partitioned_path_matches_oracle(n):
+    """n >= 2^16: radix-partitioned build with LDS sub-tables, one 8-byte gather per probe row (join_lds.hip);
+    one and two partition levels, shuffled (unsorted) build keys, a probe side of a different size"""
+    from dwarf_bench_amd import ops
+    ak = po.gen_unique_sorted_u32(n, 11)
+    np.random.default_rng(3).shuffle(ak)
+    m = n // 2 + 13
+    bk = po.gen_unique_sorted_u32(m, 12)
+    av, bv = po.gen_uniform_u32(n, 13, 0, 2**32 - 2), po.gen_uniform_u32(m, 14, 0, 2**32 - 2)
+    plan = ops.UniqueJoin(n, m)
+    plan.build(_dev(ak), _dev(av))
+    plan.probe(_dev(bk), _dev(bv))
+    ok, o1, o2 = (t.cpu().numpy().view(np.uint32) for t in plan.result())
+    ek, e1, e2 = po.ujoin(ak, av, bk, bv)
+    assert np.array_equal(ok, ek) and np.array_equal(o1, e1) and np.array_equal(o2, e2)
+    assert 0 < int((ok != 0xFFFFFFFF).sum()) < m  # hits and misses both present
+
+
+def test_ujoin_baseline_size_properties():
+    """2^26 x 2^26 unique keys in [0, 10n): every hit row carries the build payload of ITS key (payload = f(key)),
+    the number of hits equals the size of the key-set intersection (torch as an independent cross-check)"""
+    from dwarf_bench_amd import ops
+    n = 1 << 26
+    ak = ops.gen_unique_sorted_u32(n, 11)
+    bk = ops.gen_unique_sorted_u32(n, 12)
+    av = ak ^ 0x5A5A5A5A  # payload determined by the key
+    plan = ops.UniqueJoin(n, n)
+    plan.build(ak, av)
+    plan.probe(bk, bk)
+    ok, o1, o2 = plan.result()
+    hit = ok != -1
+    assert torch.equal(ok[hit], bk[hit]) and torch.equal(o1[hit], bk[hit] ^ 0x5A5A5A5A) and torch.equal(o2[hit], bk[hit])
+    assert bool((o1[~hit] == -1).all()) and bool((o2[~hit] == -1).all())
+    pos = torch.searchsorted(ak.to(torch.int64) & 0xFFFFFFFF, bk.to(torch.int64) & 0xFFFFFFFF).clamp_(max=n - 1)
+    assert int(hit.sum()) == int((ak[pos] == bk).sum())

@@ -70,6 +70,17 @@ def main():
             t = bmed + pmed
             print(f"join n=2^{lg}: build {bmed:.0f} us probe {pmed:.0f} us total {t:.0f} us  {2*n/t:.0f} Mrows/s  20N-roofline {20*n/t/1e6/8*100:.2f}%")
             del plan
+    if "ujoin" in which:
+        for lg in (20, 24, 26):
+            n = 1 << lg
+            ak, bk = ops.gen_unique_sorted_u32(n, 11), ops.gen_unique_sorted_u32(n, 12)
+            plan = ops.UniqueJoin(n, n)
+            bmn, bmed = timeit(lambda: plan.build(ak, ak), iters=5, warm=1)
+            pmn, pmed = timeit(lambda: plan.probe(bk, bk), iters=5, warm=1)
+            plan.result()
+            t = bmed + pmed
+            print(f"ujoin n=2^{lg}: build {bmed:.0f} us probe {pmed:.0f} us total {t:.0f} us  {2*n/t:.0f} Mrows/s")
+            del plan
     if "reduce" in which:
         for lg in (20, 24, 28):
             n = 1 << lg
