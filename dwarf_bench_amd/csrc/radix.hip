@@ -9,7 +9,7 @@
 //   2. rs_plan           one workgroup: per pass the exclusive digit bases, and which passes are skipped
 //                        because their digit is constant over the whole input (e.g. keys in [1,10000]
 //                        skip the two upper bytes); fixes the ping-pong parity of every pass.
-//   3. per executed pass, three kernels over CHUNKS of consecutive 4096-key tiles, with no communication
+//   3. per executed pass, three kernels over CHUNKS of consecutive 8192-key tiles, with no communication
 //      between workgroups inside a kernel:
 //        rs_chunk_hist     digit counts of every chunk (LDS histogram) -> counts[digit][chunk]
 //        rs_chunk_scan     one workgroup per digit: exclusive scan of its row + the digit base
@@ -31,11 +31,15 @@
 namespace dbhip {
 namespace {
 
-constexpr int kRsThreads = 256;
+#ifndef DBHIP_RS_THREADS
+#define DBHIP_RS_THREADS 512
+#endif
+constexpr int kRsThreads = DBHIP_RS_THREADS;
 constexpr int kRsWaves = kRsThreads / kWave;
 // Tile shape of the scatter kernel (compile-time knobs for experiments).  Measured at 2^24 full-range keys, 8-bit:
 // 16 keys/lane at 4 waves/SIMD (128 VGPRs) 356 us; 8 keys/lane at 6 waves/SIMD (80 VGPRs) 379 us; 8 at 8 (spills)
-// 443 us; 16 at 5 (spills) 553 us — more resident waves with narrower tiles do not pay.
+// 443 us; 16 at 5 (spills) 553 us — more resident waves with narrower tiles do not pay.  Workgroup width (tile =
+// threads x keys/lane): 256 threads 356 us, 512 threads (8192-key tiles, 32-key digit runs) 336 us, 1024 threads 426 us.
 #ifndef DBHIP_RS_KPT
 #define DBHIP_RS_KPT 16
 #endif
@@ -44,7 +48,7 @@ constexpr int kRsWaves = kRsThreads / kWave;
 #endif
 constexpr int kRsKpt = DBHIP_RS_KPT;             // keys per lane per tile
 constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
-constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 4096 keys
+constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
 constexpr int kRsMaxPasses = 8;
 constexpr int kRsMaxRadix = 256;
 constexpr size_t kRsTargetChunks = 2048;         // chunks per pass (>= 8 per CU for balance)
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
   hi = hi < n ? hi : n;
   for (int i = threadIdx.x; i < kRadix; i += kRsThreads) s_hist[i] = 0;
   __syncthreads();
-  // chunk starts are multiples of 4096 keys: 16-byte loads are aligned
+  // chunk starts are multiples of the tile size: 16-byte loads are aligned
   const size_t n4 = (hi - lo) / 4;
   const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
   for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
