@@ -343,6 +343,101 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   }
 }
 
+// ---- n <= one tile: the whole sort in ONE workgroup and one launch ------------------------------------------
+// (the reference's small sweeps and dwarf tests run 128..65536 keys, where the ~16 launches of the general path
+// are all that is measured).  Keys stay in registers between passes; every pass ranks them exactly as the
+// scatter kernel does and re-orders them through LDS; passes whose digit is constant over the input are skipped
+// on a workgroup-uniform vote; the result is written back to `keys`.
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kernel(unsigned *keys, unsigned n,
+                                                                                  unsigned xor_mask) {
+  constexpr int kRadix = 1 << BITS;
+  constexpr int kPasses = 32 / BITS;
+  __shared__ unsigned s_cnt[kRsWaves][kRadix];
+  __shared__ unsigned s_dexcl[kRadix];
+  __shared__ unsigned s_wsum[kRsWaves];
+  __shared__ unsigned s_keys[kRsTile];
+  __shared__ unsigned s_or, s_and;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned long long lanes_lt = (1ull << lane) - 1ull;
+  const unsigned wave_first = wave * kRsWaveKeys + lane;
+
+  unsigned key[kRsKpt];
+  unsigned my_or = 0, my_and = ~0u;
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    const unsigned idx = wave_first + j * kWave;
+    key[j] = idx < n ? keys[idx] : 0xFFFFFFFFu;
+    if (idx < n) {
+      my_or |= key[j];
+      my_and &= key[j];
+    }
+  }
+  if (tid == 0) {
+    s_or = 0;
+    s_and = ~0u;
+  }
+  __syncthreads();
+  atomicOr(&s_or, my_or);
+  atomicAnd(&s_and, my_and);
+  __syncthreads();
+  const unsigned varying = s_or ^ s_and;  // bits that differ somewhere in the input
+
+  for (int pass = 0; pass < kPasses; ++pass) {
+    const int shift = pass * BITS;
+    if (((varying >> shift) & (kRadix - 1)) == 0) continue;  // constant digit: the pass is the identity
+    for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    unsigned rank[kRsKpt];
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      const bool valid = wave_first + j * kWave < n;
+      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      const unsigned long long m = match_digit<BITS>(d) & __ballot(valid);
+      const unsigned prior = __builtin_popcountll(m & lanes_lt);
+      const unsigned c = s_cnt[wave][d];
+      rank[j] = c + prior;
+      if (valid && prior == 0) s_cnt[wave][d] = c + __builtin_popcountll(m);
+    }
+    __syncthreads();
+    unsigned tile_count = 0;
+    if (tid < kRadix) {
+#pragma unroll
+      for (int w = 0; w < kRsWaves; ++w) {
+        const unsigned c = s_cnt[w][tid];
+        s_cnt[w][tid] = tile_count;
+        tile_count += c;
+      }
+    }
+    const unsigned incl = wave_inclusive_scan(tile_count);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned dexcl = incl - tile_count;
+    for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
+    if (tid < kRadix) s_dexcl[tid] = dexcl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      if (wave_first + j * kWave < n) {
+        const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+        s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      const unsigned idx = wave_first + j * kWave;
+      key[j] = idx < n ? s_keys[idx] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    const unsigned idx = wave_first + j * kWave;
+    if (idx < n) keys[idx] = key[j];
+  }
+}
+
 __global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ tmp,
                                                                  size_t n, const RsHeader *hdr) {
@@ -368,6 +463,13 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
   unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
 
+  if (n <= static_cast<size_t>(kRsTile)) {  // one tile: one workgroup, one launch (+ the status word)
+    const hipError_t e0 = fill_async(workspace, 0, kWsHeader, s);
+    if (e0 != hipSuccess) return static_cast<int>(e0);
+    hipLaunchKernelGGL((rs_single_tile_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, keys, static_cast<unsigned>(n),
+                       xor_mask);
+    return launch_status();
+  }
   hipError_t e = fill_async(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
   if (e != hipSuccess) return static_cast<int>(e);
 

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("bits", [8, 4])
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100003, 1 << 20])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 100003, 1 << 20])
 def test_sort_u32_full_range(n, bits):
     from dwarf_bench_amd import ops
     keys = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
