@@ -8,7 +8,7 @@
 // > 800 G/s.  So:
 //   build  1. partition the build column into K = n/2048 partitions by the HIGH bits of the mixed hash,
 //             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
-//             one global reservation per bucket per 4096-key tile, runs written contiguously);
+//             one global reservation per bucket per 8192-key tile, runs written contiguously);
 //          2. one workgroup per partition (jl_build): 4096-slot sub-table in LDS — ds_cmpst claim of
 //             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
 //             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
@@ -31,9 +31,13 @@ namespace dbhip {
 namespace {
 
 constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
-constexpr int kJlThreads = 256;
+#ifndef DBHIP_JL_THREADS
+#define DBHIP_JL_THREADS 512
+#endif
+constexpr int kJlThreads = DBHIP_JL_THREADS;  // scatter / histogram / probe workgroups
+constexpr int kJlWaves = kJlThreads / kWave;
 constexpr int kJlKpt = 16;
-constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile
+constexpr int kJlTile = kJlThreads * kJlKpt;  // 8192 rows per scatter tile (256 threads / 4096 rows: build 4 % slower)
 constexpr int kJlBuildThreads = 512;
 
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
@@ -51,7 +55,7 @@ __device__ __forceinline__ unsigned jl_pid_sel(unsigned key, unsigned parts) {
 }
 
 // ---- level 0: histogram per (tile group, bucket) --------------------------------------------------
-// The column's 4096-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
+// The column's 8192-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
 // of every bucket (its rows' share), so the scatter's reservations on one cursor come from 1/64 of
 // the tiles: 16384 tiles bumping the SAME 128 cursors serialise on the memory-side atomic unit
 // (measured: 544 us for a 768 MiB scatter).
@@ -163,14 +167,14 @@ __global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned 
   if (b == k1 - 1 && tid == 0) starts1[static_cast<size_t>(k1) * k2] = starts0[k1];
 }
 
-// Scatter of one 4096-row tile into `nb` (<= 1024) buckets, staged through LDS so that the global
+// Scatter of one 8192-row tile into `nb` (<= 1024) buckets, staged through LDS so that the global
 // writes are runs: rows are ranked inside their bucket with LDS atomics, the tile is re-ordered by
 // bucket in LDS, every bucket's run gets ONE global reservation, and consecutive lanes then write
 // consecutive addresses of a run.  LEVEL selects how the bucket is recomputed from the key on the way
 // out (0: pid >> arg, 1: pid & arg).  dest[j] == nb marks an invalid (out-of-range) row.
 // LDS: cnt[nb] | excl[nb] | base[nb] (u64) | keys[4096] | rids[4096] | 4 wave sums.
 constexpr size_t jl_scatter_lds_bytes(unsigned nb) {
-  return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + 16;
+  return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + sizeof(unsigned) * kJlWaves;
 }
 template <int LEVEL, bool RANK = false>
 __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], const unsigned (&rid)[kJlKpt],
@@ -206,7 +210,9 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   __syncthreads();
   unsigned run = incl - mine;
   for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
-  const unsigned total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  unsigned total = 0;
+#pragma unroll
+  for (int w = 0; w < kJlWaves; ++w) total += s_wsum[w];
 #pragma unroll
   for (unsigned u = 0; u < 4; ++u) {
     const unsigned b = tid * per + u;
@@ -279,7 +285,7 @@ __device__ __forceinline__ bool jl_locate(const unsigned long long *__restrict__
 }
 
 // level-1 histogram: kJlHist1WgPerBucket workgroups stride over one level-0 bucket (four independent loads per
-// lane per step), so a bucket's k2 counters see 16 flushes instead of one per 4096-row tile
+// lane per step), so a bucket's k2 counters see 16 flushes instead of one per scatter tile
 constexpr unsigned kJlHist1WgPerBucket = 16;
 
 __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__restrict__ keys,
