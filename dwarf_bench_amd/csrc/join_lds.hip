@@ -360,8 +360,36 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     lc[i] = 0;
   }
   __syncthreads();
-  // 1. claim the key's slot (ds_cmpst) and count the row (ds_add)
-  for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
+  // 1. claim the key's slot (ds_cmpst) and count the row (ds_add).  The slot and row id of a thread's first
+  //    kJlCached rows stay in registers for step 3 (a partition holds ~2048 rows = 4 per thread).
+  constexpr int kJlCached = 8;
+  unsigned c_slot[kJlCached], c_rid[kJlCached];
+#pragma unroll
+  for (int r = 0; r < kJlCached; ++r) {
+    const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+    c_slot[r] = kJlSubSlots;  // "no row"
+    c_rid[r] = 0;
+    if (i < hi) {
+      const unsigned key = pkeys[i];
+      c_rid[r] = prids[i];
+      unsigned s = fmix32(key) & kJlSubMask;
+      unsigned tries = 0;
+      while (true) {
+        const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
+        if (old == kEmptyKey || old == key) {
+          atomicAdd(&lc[s], 1u);
+          c_slot[r] = s;
+          break;
+        }
+        s = (s + 1) & kJlSubMask;
+        if (++tries > kJlSubMask) {
+          atomicOr(status, DBHIP_DEV_TABLE_FULL);
+          break;
+        }
+      }
+    }
+  }
+  for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
     const unsigned key = pkeys[i];
     unsigned s = fmix32(key) & kJlSubMask;
     unsigned tries = 0;
@@ -398,8 +426,11 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     run += c[j];
   }
   __syncthreads();
-  // 3. fill: ids[pos[slot]++] = row id (the partition's rows are still in L2)
-  for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
+  // 3. fill: ids[pos[slot]++] = row id — from the registers of step 1, the overflow rows are read again
+#pragma unroll
+  for (int r = 0; r < kJlCached; ++r)
+    if (c_slot[r] < kJlSubSlots) ids[atomicAdd(&lp[c_slot[r]], 1u)] = c_rid[r];
+  for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
     const unsigned key = pkeys[i];
     unsigned s = fmix32(key) & kJlSubMask;
     for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
