@@ -1,0 +1,50 @@
+"""The bench line's schema (the driver's contract + roofline + cpu_baseline), checked on the committed N=1 line of
+this round (profiles/r01_bench_n1.json) and on bench.py's argument defaults.  No GPU needed."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"] == json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    assert line["unit"] == "Mrows/s" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["n_gpus"] == 1 and line["data"] == "synthetic" and line["dtype"] == "int32"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(roof["achieved"] - roof["algorithmic_bytes"] / roof["kernel_us_avg"] / 1e3) < 1e-6 * roof["achieved"]
+    assert roof["traffic"] is None or roof["traffic"] >= 0.99 * roof["algorithmic_bytes"]
+    # value = rows / wall time of a step
+    assert abs(line["value"] - line["config"]["rows"] / (line["ms_per_step"] * 1e3)) < 1e-6 * line["value"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["unit"] == "Mrows/s" and cpu["sample"]
+    assert line["parity_check"] is True
+    for name in ("sort_8bit", "sort_4bit", "groupby", "join", "pjoin_p1"):
+        assert name in line["dwarfs"], name
+
+
+def test_bench_defaults_and_help():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
+    src = (ROOT / "bench.py").read_text()
+    assert 'add_argument("--gpus", type=int, default=1)' in src
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """the product has no CPU path: bench.py must say so instead of measuring something else"""
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
