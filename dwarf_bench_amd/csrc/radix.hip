@@ -84,18 +84,30 @@ inline RsGeometry rs_geometry(size_t n) {
   return g;
 }
 
-// lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA)
+// lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA).  Per bit and 32-lane
+// half: sel = bit ? ballot : ~ballot = ~(ballot ^ (bit ? ~0 : 0)), one v_xnor_b32 on the sign-extended bit
+// (v_bfe_i32), then one v_and — 6 vector instructions per bit where the obvious `bit ? bal : ~bal` on 64-bit values
+// compiled to 9 (the scatter kernel is VALU-bound, so this is its critical path).
+struct LaneMask {
+  unsigned lo, hi;
+};
 template <int BITS>
-__device__ __forceinline__ unsigned long long match_digit(unsigned d) {
-  unsigned long long m = ~0ull;
+__device__ __forceinline__ LaneMask match_digit(unsigned d) {
+  LaneMask m{~0u, ~0u};
 #pragma unroll
   for (int b = 0; b < BITS; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
+    const unsigned nb = static_cast<unsigned>(__builtin_amdgcn_sbfe(d, b, 1));  // bit b of d as 0 / 0xFFFFFFFF
+    const unsigned long long bal = __ballot(nb != 0u);
+    m.lo &= ~(static_cast<unsigned>(bal) ^ nb);
+    m.hi &= ~(static_cast<unsigned>(bal >> 32) ^ nb);
   }
   return m;
 }
+// number of set mask bits below my lane / in the whole mask
+__device__ __forceinline__ unsigned lanes_before(LaneMask m) {
+  return __builtin_amdgcn_mbcnt_hi(m.hi, __builtin_amdgcn_mbcnt_lo(m.lo, 0u));
+}
+__device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popcount(m.lo) + __builtin_popcount(m.hi); }
 
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
@@ -238,6 +250,90 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
 }
 
 // ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
+// One tile of the scatter: stable rank inside each wave, digit offsets across waves, re-order through LDS, write out
+// in digit order.  FULL = the tile holds kRsTile keys: no per-key bounds checks (the kernel is VALU-bound — about 100
+// vector instructions per 64 keys, 80 % of the issue slots at 2^24 keys by the SQ counters).
+template <int BITS, bool FULL>
+__device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src, unsigned *__restrict__ dst,
+                                                size_t tile_base, unsigned valid_in_tile, int shift, unsigned xor_mask,
+                                                unsigned &running, unsigned (*s_cnt)[1 << BITS], unsigned *s_dexcl,
+                                                unsigned *s_goff, unsigned *s_wsum, unsigned *s_keys) {
+  constexpr int kRadix = 1 << BITS;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned wave_first = wave * kRsWaveKeys + lane;
+  unsigned key[kRsKpt];
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    const unsigned idx = wave_first + j * kWave;
+    key[j] = (FULL || idx < valid_in_tile) ? src[tile_base + idx] : 0xFFFFFFFFu;
+  }
+  for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+  __syncthreads();
+
+  // ---- stable rank of every key among the keys of its wave with the same digit
+  unsigned rank[kRsKpt];
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    const bool valid = FULL || wave_first + j * kWave < valid_in_tile;
+    const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+    LaneMask m = match_digit<BITS>(d);
+    if (!FULL) {
+      const unsigned long long v = __ballot(valid);
+      m.lo &= static_cast<unsigned>(v);
+      m.hi &= static_cast<unsigned>(v >> 32);
+    }
+    const unsigned prior = lanes_before(m);
+    const unsigned c = s_cnt[wave][d];  // same address inside a digit group: LDS broadcast
+    rank[j] = c + prior;
+    if (valid && prior == 0) s_cnt[wave][d] = c + lanes_in(m);  // group leader
+  }
+  __syncthreads();
+
+  // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals
+  unsigned tile_count = 0;
+  if (tid < kRadix) {
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) {
+      const unsigned c = s_cnt[w][tid];
+      s_cnt[w][tid] = tile_count;
+      tile_count += c;
+    }
+  }
+  const unsigned incl = wave_inclusive_scan(tile_count);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned dexcl = incl - tile_count;
+  for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
+  if (tid < kRadix) {
+    s_dexcl[tid] = dexcl;
+    s_goff[tid] = running - dexcl;
+    running += tile_count;
+  }
+  __syncthreads();
+
+  // ---- re-order the tile by digit in LDS
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    if (FULL || wave_first + j * kWave < valid_in_tile) {
+      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- write out in digit order: consecutive lanes -> consecutive addresses inside a digit run
+#pragma unroll
+  for (int k = 0; k < kRsKpt; ++k) {
+    const unsigned p = k * kRsThreads + tid;
+    if (FULL || p < valid_in_tile) {
+      const unsigned kk = s_keys[p];
+      const unsigned d = ((kk ^ xor_mask) >> shift) & (kRadix - 1);
+      dst[s_goff[d] + p] = kk;
+    }
+  }
+  __syncthreads();
+}
+
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
                                                                          int pass, unsigned xor_mask,
@@ -257,8 +353,7 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   unsigned *__restrict__ dst = plan.src_is_tmp ? keys : tmp;
   const int shift = pass * BITS;
 
-  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const unsigned long long lanes_lt = (1ull << lane) - 1ull;
+  const unsigned tid = threadIdx.x;
   const size_t chunk = blockIdx.x;
   const size_t first_tile = chunk * tiles_per_chunk;
   const size_t total_tiles = (n + kRsTile - 1) / kRsTile;
@@ -267,79 +362,17 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   // digit owners keep the chunk's running global offset of their digit in a register
   unsigned running = tid < kRadix ? offsets[static_cast<size_t>(tid) * num_chunks + chunk] : 0u;
 
-  const unsigned wave_first = wave * kRsWaveKeys + lane;
   // (prefetching the next tile's keys into a second register set was measured: it needs 3 waves/SIMD
   //  instead of 4 to avoid spills and came out 7 % slower at 2^24 keys)
   for (size_t tile = first_tile; tile < last_tile; ++tile) {
     const size_t tile_base = tile * kRsTile;
     const unsigned valid_in_tile = static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
-
-    unsigned key[kRsKpt];
-#pragma unroll
-    for (int j = 0; j < kRsKpt; ++j) {
-      const unsigned idx = wave_first + j * kWave;
-      key[j] = idx < valid_in_tile ? src[tile_base + idx] : 0xFFFFFFFFu;
-    }
-    for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
-
-    // ---- stable rank of every key among the keys of its wave with the same digit
-    unsigned rank[kRsKpt];
-#pragma unroll
-    for (int j = 0; j < kRsKpt; ++j) {
-      const bool valid = wave_first + j * kWave < valid_in_tile;
-      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-      const unsigned long long m = match_digit<BITS>(d) & __ballot(valid);
-      const unsigned prior = __builtin_popcountll(m & lanes_lt);
-      const unsigned c = s_cnt[wave][d];  // same address inside a digit group: LDS broadcast
-      rank[j] = c + prior;
-      if (valid && prior == 0) s_cnt[wave][d] = c + __builtin_popcountll(m);  // group leader
-    }
-    __syncthreads();
-
-    // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals
-    unsigned tile_count = 0;
-    if (tid < kRadix) {
-#pragma unroll
-      for (int w = 0; w < kRsWaves; ++w) {
-        const unsigned c = s_cnt[w][tid];
-        s_cnt[w][tid] = tile_count;
-        tile_count += c;
-      }
-    }
-    const unsigned incl = wave_inclusive_scan(tile_count);
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned dexcl = incl - tile_count;
-    for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
-    if (tid < kRadix) {
-      s_dexcl[tid] = dexcl;
-      s_goff[tid] = running - dexcl;
-      running += tile_count;
-    }
-    __syncthreads();
-
-    // ---- re-order the tile by digit in LDS
-#pragma unroll
-    for (int j = 0; j < kRsKpt; ++j) {
-      if (wave_first + j * kWave < valid_in_tile) {
-        const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-        s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
-      }
-    }
-    __syncthreads();
-
-    // ---- write out in digit order: consecutive lanes -> consecutive addresses inside a digit run
-#pragma unroll
-    for (int k = 0; k < kRsKpt; ++k) {
-      const unsigned p = k * kRsThreads + tid;
-      if (p < valid_in_tile) {
-        const unsigned kk = s_keys[p];
-        const unsigned d = ((kk ^ xor_mask) >> shift) & (kRadix - 1);
-        dst[s_goff[d] + p] = kk;
-      }
-    }
-    __syncthreads();
+    if (valid_in_tile == kRsTile)  // every tile but the input's last one
+      rs_scatter_tile<BITS, true>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
+                                  s_wsum, s_keys);
+    else
+      rs_scatter_tile<BITS, false>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
+                                   s_wsum, s_keys);
   }
 }
 
@@ -359,7 +392,6 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
   __shared__ unsigned s_keys[kRsTile];
   __shared__ unsigned s_or, s_and;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const unsigned long long lanes_lt = (1ull << lane) - 1ull;
   const unsigned wave_first = wave * kRsWaveKeys + lane;
 
   unsigned key[kRsKpt];
@@ -393,11 +425,14 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
     for (int j = 0; j < kRsKpt; ++j) {
       const bool valid = wave_first + j * kWave < n;
       const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-      const unsigned long long m = match_digit<BITS>(d) & __ballot(valid);
-      const unsigned prior = __builtin_popcountll(m & lanes_lt);
+      LaneMask m = match_digit<BITS>(d);
+      const unsigned long long v = __ballot(valid);
+      m.lo &= static_cast<unsigned>(v);
+      m.hi &= static_cast<unsigned>(v >> 32);
+      const unsigned prior = lanes_before(m);
       const unsigned c = s_cnt[wave][d];
       rank[j] = c + prior;
-      if (valid && prior == 0) s_cnt[wave][d] = c + __builtin_popcountll(m);
+      if (valid && prior == 0) s_cnt[wave][d] = c + lanes_in(m);
     }
     __syncthreads();
     unsigned tile_count = 0;
