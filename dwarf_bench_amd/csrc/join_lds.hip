@@ -357,9 +357,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
                                                                    unsigned n_rows,
                                                                    unsigned *__restrict__ ids, unsigned *status) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
-  unsigned *lk = s_lds;                  // keys
-  unsigned *lc = s_lds + kJlSubSlots;    // counts
-  unsigned *lp = s_lds + 2 * kJlSubSlots;  // positions (start, then bumped to end by the fill)
+  unsigned *lk = s_lds;                // keys
+  unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
+  unsigned *lp = lc;                   // first id position of the slot, bumped to its end by the fill.
+  // (two 16 KiB arrays instead of three: 4 workgroups per CU instead of 3)
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const size_t part = blockIdx.x;
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
   __syncthreads();
   unsigned run = static_cast<unsigned>(lo) + incl - mine;
   for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+  // every thread has its 8 counts in registers (the barrier above): overwrite them with the positions
 #pragma unroll
   for (unsigned j = 0; j < kPer; ++j) {
     lp[tid * kPer + j] = run;
@@ -447,9 +449,11 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = prids[i];
   }
   __syncthreads();
-  // 4. publish the sub-table: {key, first position} for every slot (the fill bumped lp[] by the count)
+  // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot i's
+  //    ids, and positions are an exclusive scan in slot order, so slot i starts where slot i-1 ends.
   u32x2 *dst = table + part * kJlSubSlots;
-  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) dst[i] = u32x2{lk[i], lp[i] - lc[i]};
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads)
+    dst[i] = u32x2{lk[i], i ? lp[i - 1] : static_cast<unsigned>(lo)};
   if (part + 1 == parts && tid == 0) dst[kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // right neighbour of the last slot
 }
 
@@ -637,7 +641,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   JlPartitioned p;
   const int rc = jl_partition_rows(build_keys, row_ids, n, workspace, s, dev, L, &p);
   if (rc != 0) return rc;
-  const size_t build_lds = 3 * kJlSubSlots * sizeof(unsigned);
+  const size_t build_lds = 2 * kJlSubSlots * sizeof(unsigned);
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
