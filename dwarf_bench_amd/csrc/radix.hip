@@ -355,7 +355,12 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   const int shift = pass * BITS;
 
   const unsigned tid = threadIdx.x;
-  const size_t chunk = blockIdx.x;
+  // XCD-aware chunk order (speed only): workgroups go to the 8 XCDs round-robin by blockIdx; XCD x takes the x-th
+  // eighth of the chunks, so neighbouring chunks — whose digit runs are neighbours in the output and share the
+  // partial lines at their ends — are written through the same L2.
+  const size_t per_xcd = (num_chunks + 7) / 8;
+  const size_t chunk = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+  if (chunk >= num_chunks || blockIdx.x / 8u >= per_xcd) return;
   const size_t first_tile = chunk * tiles_per_chunk;
   const size_t total_tiles = (n + kRsTile - 1) / kRsTile;
   size_t last_tile = first_tile + tiles_per_chunk;
@@ -521,7 +526,7 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
                        hdr, counts, g.tiles_per_chunk, g.chunks);
     hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
                        g.chunks);
-    hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+    hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys, tmp, n, p,
                        xor_mask, hdr, counts, g.tiles_per_chunk, g.chunks);
   }
   hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
