@@ -25,6 +25,11 @@
  *   dbhip_join_*              common/dpcpp/omnisci_hashtable.hpp:58-261 <- join/join_omnisci.cpp:74-88
  *   dbhip_ujoin_*             join/join.cpp:60-104, common/dpcpp/hashtable.hpp:5-93,
  *                             common/dpcpp/hashfunctions.hpp:64-137 (MurmurHash3_x86_32)
+ *   dbhip_groupby_partial/merge_u32  groupby/groupby_local.cpp:52-112 (the two timed phases of GroupByLocal)
+ *   dbhip_bitmask_table_*     common/dpcpp/hashtable.hpp:5-93 (SimpleNonOwningHashTable) <- hash/hash_build.cpp:8-98,
+ *                             join/join.cpp:30-38, tests/hash_table_tests.cpp
+ *   dbhip_reduce_sum_i32      reduce/reduce.cpp:27-88
+ *   dbhip_nested_join_u32     join/nested_join.cpp:52-66
  *   dbhip_pjoin_*             no reference counterpart (multi-GPU radix-partitioned join)
  *   dbhip_gen_*               common/common.hpp:31-40, common/common.cpp:7-20 (data generators)
  */
@@ -73,7 +78,9 @@ int dbhip_gen_unique_sorted_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t
 
 /* ---- dwarf 1: scan / stream compaction --------------------------------------------------------
  * out[0..*out_size) = [x in src : x < filter_value] in source order (stable), *out_size = count.
- * One pass over src (decoupled look-back); `out` needs room for n elements in the worst case.
+ * src is read ONCE: below 2^22 elements a single-pass kernel with decoupled look-back; above, a chunked
+ * kernel stages each chunk's matches in the workspace (which therefore holds n elements) and a second
+ * small kernel moves them to their final offsets.  `out` needs room for n elements in the worst case.
  * out_size is a DEVICE pointer to one uint64.                                                    */
 size_t dbhip_copy_if_lt_i32_workspace_bytes(size_t n);
 int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,
