@@ -8,7 +8,7 @@
 // > 800 G/s.  So:
 //   build  1. partition the build column into K = n/2048 partitions by the HIGH bits of the mixed hash,
 //             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
-//             one global reservation per bucket per 8192-key tile, runs written contiguously);
+//             one global reservation per bucket per 4096-key tile, runs written contiguously);
 //          2. one workgroup per partition (jl_build): 4096-slot sub-table in LDS — ds_cmpst claim of
 //             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
 //             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
@@ -36,8 +36,13 @@ constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
 #endif
 constexpr int kJlThreads = DBHIP_JL_THREADS;  // scatter / histogram / probe workgroups
 constexpr int kJlWaves = kJlThreads / kWave;
-constexpr int kJlKpt = 16;
-constexpr int kJlTile = kJlThreads * kJlKpt;  // 8192 rows per scatter tile (256 threads / 4096 rows: build 4 % slower)
+#ifndef DBHIP_JL_KPT
+#define DBHIP_JL_KPT 8
+#endif
+constexpr int kJlKpt = DBHIP_JL_KPT;
+constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile, 36 KiB of LDS: four 512-thread workgroups
+                                              // per CU.  Measured at 2^26 rows (build, us): 512x8 1361, 512x16 1423,
+                                              // 1024x8 1390, 512x4 1442, 256x8 1499, 512x32 1687
 constexpr int kJlBuildThreads = 512;
 
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
@@ -55,7 +60,7 @@ __device__ __forceinline__ unsigned jl_pid_sel(unsigned key, unsigned parts) {
 }
 
 // ---- level 0: histogram per (tile group, bucket) --------------------------------------------------
-// The column's 8192-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
+// The column's 4096-row tiles are cut into kJlGroups contiguous groups; every group owns a private slice
 // of every bucket (its rows' share), so the scatter's reservations on one cursor come from 1/64 of
 // the tiles: 16384 tiles bumping the SAME 128 cursors serialise on the memory-side atomic unit
 // (measured: 544 us for a 768 MiB scatter).
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned 
   if (b == k1 - 1 && tid == 0) starts1[static_cast<size_t>(k1) * k2] = starts0[k1];
 }
 
-// Scatter of one 8192-row tile into `nb` (<= 1024) buckets, staged through LDS so that the global
+// Scatter of one 4096-row tile into `nb` (<= 1024) buckets, staged through LDS so that the global
 // writes are runs: rows are ranked inside their bucket with LDS atomics, the tile is re-ordered by
 // bucket in LDS, every bucket's run gets ONE global reservation, and consecutive lanes then write
 // consecutive addresses of a run.  LEVEL selects how the bucket is recomputed from the key on the way
