@@ -687,6 +687,9 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
 }
 
 // ---- stand-alone level-0 partition (multi-GPU join: bucket = destination rank) ------------------------
+// 2^27 rows into 8 buckets: histogram 158 us + scatter 566 us (into 2 buckets: 285 + 700 us — the LDS atomics of a
+// wave land on very few addresses).  Counting and ranking by ballot in wave-uniform registers instead (16 unrolled
+// bucket tests per key) was measured at 324 + 794 us and dropped.
 size_t jl_partition_workspace_bytes(unsigned parts) {
   return align_up(kWsHeader + sizeof(unsigned long long) * ((2 * static_cast<size_t>(kJlGroups) + 2) * parts + 2),
                   kWsAlign);
