@@ -103,3 +103,22 @@ def test_stress_under_uneven_load():
         got = ops.copy_if_lt(src, 50)
         assert np.array_equal(got.cpu().numpy(), exp), it
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("log2n,extra,filt", [(31, 5, 5), (30, 12345, 5001)])
+def test_beyond_32_bit_byte_offsets(log2n, extra, filt):
+    """n * 4 bytes > 4 GiB: 64-bit indexing everywhere (torch's boolean indexing as the independent check)"""
+    from dwarf_bench_amd import ops
+    n = (1 << log2n) + extra
+    src = ops.gen_uniform_u32(n, 77, 1, 10000)
+    plan = ops.CopyIfLt(n)
+    plan.launch(src, filt)
+    got = plan.result()
+    # compare piecewise to bound the temporary memory of the torch reference
+    step, off = 1 << 28, 0
+    for lo in range(0, n, step):
+        part = src[lo: lo + step]
+        want = part[part < filt]
+        assert torch.equal(got[off: off + want.numel()], want), lo
+        off += want.numel()
+    assert off == got.numel()
