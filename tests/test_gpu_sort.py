@@ -72,3 +72,24 @@ def test_sort_2_24_baseline_config(bits):
     host = sample.cpu().numpy().view(np.uint32)
     ops.radix_sort_(sample, radix_bits=bits)
     assert np.array_equal(sample.cpu().numpy().view(np.uint32), po.sort_u32(host))
+
+
+def test_large_input_properties_2_30():
+    """2^30 + 3 keys (4 GiB): sorted, same multiset (order-independent checksums), 64 tiles per chunk"""
+    from dwarf_bench_amd import ops
+    n = (1 << 30) + 3
+    keys = ops.gen_uniform_u32(n, 5, 0, 2**32 - 1)
+    s0 = int(keys.to(torch.int64).sum().item())
+    plan = ops.RadixSort(n, 8)
+    plan.launch(keys)
+    torch.cuda.synchronize()
+    assert ops.workspace_status(plan.ws) == 0
+    step = 1 << 28
+    for lo in range(0, n - 1, step):  # unsigned order: compare in int64 with the sign bit folded
+        a = keys[lo: min(lo + step + 1, n)].to(torch.int64) & 0xFFFFFFFF
+        assert bool((a[1:] >= a[:-1]).all()), lo
+    assert int(keys.to(torch.int64).sum().item()) == s0
+    # the histogram of the top byte is preserved and matches a uniform draw
+    top = (keys.to(torch.int64) & 0xFFFFFFFF) >> 24
+    c = torch.bincount(top, minlength=256)
+    assert int(c.sum()) == n and float(c.max()) / float(c.min()) < 1.01
