@@ -87,8 +87,9 @@ inline RsGeometry rs_geometry(size_t n) {
 
 // lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA).  Per bit and 32-lane
 // half: sel = bit ? ballot : ~ballot = ~(ballot ^ (bit ? ~0 : 0)), one v_xnor_b32 on the sign-extended bit
-// (v_bfe_i32), then one v_and — 6 vector instructions per bit where the obvious `bit ? bal : ~bal` on 64-bit values
-// compiled to 9 (the scatter kernel is VALU-bound, so this is its critical path).
+// (v_bfe_i32) folded with the running mask into one v_bitop3_b32 — 4 vector instructions per bit (v_bfe_i32, v_cmp,
+// 2 x v_bitop3) where the obvious `bit ? bal : ~bal` on 64-bit values compiled to 9 (the scatter kernel is
+// VALU-bound, so this is its critical path).
 struct LaneMask {
   unsigned lo, hi;
 };
@@ -99,8 +100,9 @@ __device__ __forceinline__ LaneMask match_digit(unsigned d) {
   for (int b = 0; b < BITS; ++b) {
     const unsigned nb = static_cast<unsigned>(__builtin_amdgcn_sbfe(d, b, 1));  // bit b of d as 0 / 0xFFFFFFFF
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(static_cast<int>(nb) < 0);
-    m.lo &= ~(static_cast<unsigned>(bal) ^ nb);
-    m.hi &= ~(static_cast<unsigned>(bal >> 32) ^ nb);
+    // m & ~(bal ^ nb) in one three-input boolean op per half (v_bitop3_b32, truth table 0x90 over (m, bal, nb))
+    m.lo = __builtin_amdgcn_bitop3_b32(m.lo, static_cast<unsigned>(bal), nb, 0x90);
+    m.hi = __builtin_amdgcn_bitop3_b32(m.hi, static_cast<unsigned>(bal >> 32), nb, 0x90);
   }
   return m;
 }

@@ -6,7 +6,7 @@ from dwarf_bench_amd import ops
 n = 1 << 24
 keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
 keys = keys0.clone()
-plan = ops.RadixSort(n, 8)
+plan = ops.RadixSort(n, int(os.environ.get("SORT_BITS", "8")))
 for _ in range(3):
     keys.copy_(keys0)
     plan.launch(keys)
