@@ -216,6 +216,20 @@ def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
             "workload": f"radix-partitioned HashJoin 2^{log2_total} x 2^{log2_total} uint32 keys over {world} GPU(s)"}
 
 
+def scan_selectivity_sweep(src, plan, n):
+    """SURVEY 8(d)'s secondary sweep: filter in {101, 1001, 5001} (selectivity ~1 %, 10 %, 50 %), 9 iterations each,
+    the reference notebook's drop-max-mean; algorithmic bytes 4*n*(1+s)."""
+    out = {}
+    for filt in (101, 1001, 5001):
+        run = lambda: plan.launch(src, filt)
+        run()
+        us = _drop_max_mean(_event_times_us(run, 9))
+        m = plan.result().numel()
+        out[str(filt)] = {"selectivity": m / n, "kernel_us": us, "mrows_per_s": n / us,
+                          "frac_of_hbm_peak": (4 * n + 4 * m) / us / 1e3 / HBM_PEAK_GBS}
+    return out
+
+
 def cpu_baseline_scan(src_dev, filt, budget_s=12.0):
     """The oracle's chunked scan (scan.cl restated, T chunks on T threads) on a bounded sample of the same column."""
     import numpy as np
@@ -366,12 +380,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline_scan(scan["src"], 5)
         else:
             out["cpu_baseline"] = None
+    sweep = scan_selectivity_sweep(scan["src"], scan["plan"], scan["rows"]) if (rank == 0 and n_gpus == 1) else None
     del scan["src"], scan["plan"]
     torch.cuda.empty_cache()
 
     if rank == 0 and n_gpus == 1 and args.dwarf in ("all", "sort", "groupby", "join"):
         k = max(3, min(args.steps, 9))  # the reference scripts use --iterations=9
         dwarfs = {"scan": {x: scan[x] for x in ("rows", "kernel_us_avg", "kernel_us_min", "mrows_per_s", "achieved_gbs")}}
+        dwarfs["scan"]["selectivity_sweep"] = sweep
         if args.dwarf in ("all", "sort"):
             dwarfs["sort_8bit"] = bench_sort(k, 2, 24, 8)
             dwarfs["sort_4bit"] = bench_sort(k, 2, 24, 4)
