@@ -2,10 +2,11 @@
 // the reference has no multi-device code; SURVEY 8(e) defines the path).
 //
 // Per GPU (one process per GPU, exchange done by the host side with RCCL all-to-all over xGMI):
-//   dbhip_pjoin_partition_u32   splits a local column shard into `parts` destination buckets by the
-//                               high bits of the mixed hash (Murmur3 finaliser, multiply-shift range
-//                               reduction, so any part count balances) and tags every key with its
-//                               GLOBAL row id.  It is the level-0 partition of the LDS join
+//   dbhip_pjoin_partition_u32   splits a local column shard into `parts` destination buckets by
+//                               fmix32(key * 0x9E3779B1 + c) (Murmur3 finaliser of an affine image of the key,
+//                               multiply-shift range reduction, so any part count balances) — a hash
+//                               independent of the one the local join partitions by (jl_rank_of, join_lds.hip)
+//                               — and tags every key with its GLOBAL row id.  It is the level-0 partition of the LDS join
 //                               (join_lds.hip: per-group histogram, bucket/group cursors, LDS-staged
 //                               scatter that writes runs) with bucket = destination rank.  Order
 //                               inside a bucket is not defined (the join does not need it).

@@ -164,8 +164,8 @@ int dbhip_bitmask_table_lookup_u32(const uint32_t *keys, size_t n, const void *w
                                    dbhip_stream_t stream);
 
 /* ---- multi-GPU radix-partitioned join: device pieces (no reference counterpart) ---------
- * Partition a local column shard into `parts` (1..256) destination buckets by the mixed hash of
- * the key: out_keys / out_row_ids are bucket-major (bucket d occupies
+ * Partition a local column shard into `parts` (1..1024) destination buckets by a mixed hash of
+ * the key (independent of the hash the local join partitions by): out_keys / out_row_ids are bucket-major (bucket d occupies
  * [sum(out_counts[0..d)), +out_counts[d])), out_row_ids[i] = first_row_id + local index of the key
  * (global row ids must fit 32 bits), out_counts is a DEVICE array of `parts` uint64.  The exchange
  * between GPUs is the host's job (RCCL all-to-all); the local join on the received pairs is
