@@ -43,7 +43,11 @@ constexpr int kJlKpt = DBHIP_JL_KPT;
 constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile, 36 KiB of LDS: four 512-thread workgroups
                                               // per CU.  Measured at 2^26 rows (build, us): 512x8 1361, 512x16 1423,
                                               // 1024x8 1390, 512x4 1442, 256x8 1499, 512x32 1687
-constexpr int kJlBuildThreads = 512;
+#ifndef DBHIP_JL_BUILD_THREADS
+#define DBHIP_JL_BUILD_THREADS 512
+#endif
+constexpr int kJlBuildThreads = DBHIP_JL_BUILD_THREADS;  // per-partition build workgroup; 2^26 rows: 512 -> 1398 us,
+                                                        // 256 -> 1514 us, 1024 -> 1465 us (whole build)
 
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
   return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key)) * parts) >> 32);
