@@ -706,7 +706,7 @@ struct PjRank {
   int device = 0;
   hipStream_t stream = nullptr;
   size_t lo = 0, n_local = 0;
-  DevMem build, probe, pk_r, pr_r, pk_s, pr_s, cnt_dev, part_ws;
+  DevMem build, probe, pk_r, pr_r, pk_s, pr_s, cnt_dev, part_ws, chk;
   size_t part_ws_bytes = 0;
   std::vector<uint64_t> send_r, send_s;  // rows for every destination rank
   size_t recv_r = 0, recv_s = 0;
@@ -758,6 +758,7 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
     k.pk_s = DevMem(k.device, col);
     k.pr_s = DevMem(k.device, col);
     k.cnt_dev = DevMem(k.device, 2 * P * sizeof(uint64_t));
+    k.chk = DevMem(k.device, 8 * sizeof(int32_t));
     k.part_ws_bytes = dbhip_pjoin_partition_workspace_bytes(k.n_local, P);
     k.part_ws = DevMem(k.device, k.part_ws_bytes);
     db_ok(dbhip_gen_uniform_u32(k.build.as<uint32_t>(), k.n_local, 42, k.lo, 0, key_hi, k.stream), "gen build");
@@ -858,9 +859,16 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
         };
         for (const Col &c : cols) {
           if (use_rccl) {
-            nccl_ok(ncclSend(c.src + c.send_off, c.send_cnt, ncclUint32, static_cast<int>(q), comms[r], me.stream), "ncclSend");
-            nccl_ok(ncclRecv(c.my_recv + c.recv_off, c.recv_cnt, ncclUint32, static_cast<int>(q), comms[r], me.stream),
-                    "ncclRecv");
+            // pieces of at most 2^28 elements (1 GiB): one ncclSend/ncclRecv of 2^29 uint32 (2 GiB) was measured to
+            // deliver garbage without any error (RCCL 2.27.7); both sides cut their segment the same way, so the
+            // k-th send to a peer still meets the k-th receive from it
+            constexpr uint64_t kPiece = 1ull << 28;
+            for (uint64_t o = 0; o < c.send_cnt; o += kPiece)
+              nccl_ok(ncclSend(c.src + c.send_off + o, std::min(kPiece, c.send_cnt - o), ncclUint32, static_cast<int>(q),
+                               comms[r], me.stream), "ncclSend");
+            for (uint64_t o = 0; o < c.recv_cnt; o += kPiece)
+              nccl_ok(ncclRecv(c.my_recv + c.recv_off + o, std::min(kPiece, c.recv_cnt - o), ncclUint32,
+                               static_cast<int>(q), comms[r], me.stream), "ncclRecv");
           } else if (c.send_cnt) {
             hip_ok(hipMemcpyPeerAsync(c.peer_recv + c.peer_recv_off, peer.device, c.src + c.send_off, me.device,
                                       c.send_cnt * sizeof(uint32_t), me.stream),
@@ -921,6 +929,31 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
       hip_ok(hipSetDevice(k.device), "hipSetDevice");
       check_status(k.join_ws.p, "PartitionedJoinHip");
       check_status(k.part_ws.p, "PartitionedJoinHip (partition)");
+    }
+    {
+      // always on, at every size: the exchange must conserve the four columns — wrap-around sums of everything sent
+      // equal the sums of everything received (device-side reduce, ~0.2 ms per GiB)
+      int32_t sent[4] = {0, 0, 0, 0}, got[4] = {0, 0, 0, 0};
+      for (PjRank &k : ranks) {
+        hip_ok(hipSetDevice(k.device), "hipSetDevice");
+        int32_t *scratch = k.chk.as<int32_t>();
+        const void *cols[8] = {k.pk_r.p, k.pr_r.p, k.pk_s.p, k.pr_s.p, k.rk.p, k.rr.p, k.sk.p, k.sr.p};
+        const size_t lens[8] = {k.n_local, k.n_local, k.n_local, k.n_local, k.recv_r, k.recv_r, k.recv_s, k.recv_s};
+        for (int c = 0; c < 8; ++c)
+          db_ok(dbhip_reduce_sum_i32(static_cast<const int32_t *>(cols[c]), lens[c], scratch + c, k.stream),
+                "dbhip_reduce_sum_i32");
+        hip_ok(hipStreamSynchronize(k.stream), "hipStreamSynchronize");
+        const auto h = d2h<int32_t>(scratch, 8, k.device);
+        for (int c = 0; c < 4; ++c) {
+          sent[c] = static_cast<int32_t>(static_cast<uint32_t>(sent[c]) + static_cast<uint32_t>(h[c]));
+          got[c] = static_cast<int32_t>(static_cast<uint32_t>(got[c]) + static_cast<uint32_t>(h[4 + c]));
+        }
+      }
+      for (int c = 0; c < 4; ++c)
+        if (sent[c] != got[c]) {
+          std::cerr << "Incorrect results (exchange did not conserve column " << c << ")" << std::endl;
+          result->valid = false;
+        }
     }
     if (validate) {
       bool ok = true;

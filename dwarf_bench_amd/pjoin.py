@@ -65,6 +65,9 @@ class PartitionedJoinResult:
     recv_probe_rows: int
 
 
+_MAX_MESSAGE_BYTES = 1 << 31
+
+
 class _Done:
     """handle of an exchange that has already completed"""
 
@@ -93,6 +96,12 @@ def _a2a(inp: torch.Tensor, out_splits, in_splits, group):
     are staged through the host there, synchronously."""
     n_out = int(sum(out_splits)) if out_splits is not None else inp.numel()
     inp = inp.contiguous()
+    # one send/recv of 2 GiB or more was measured to deliver garbage without an error through RCCL 2.27.7
+    # (PartitionedJoinHip, which therefore cuts its messages into 1 GiB pieces); torch's all_to_all_single cannot be
+    # cut from here, so refuse instead of corrupting: 2^30 x 2^30 over >= 2 ranks needs 1 GiB per message at most
+    biggest = max(list(out_splits or [0]) + list(in_splits or [0]) + [0]) * inp.element_size()
+    if biggest >= _MAX_MESSAGE_BYTES:
+        raise ValueError(f"a {biggest} byte message to one peer exceeds the {_MAX_MESSAGE_BYTES} byte limit of the exchange")
     if inp.is_cuda and dist.get_backend(group) == "gloo":
         host_out = torch.empty(n_out, dtype=inp.dtype)
         dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
