@@ -115,41 +115,61 @@ __device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popc
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
                                                                   size_t n, unsigned xor_mask,
-                                                                  unsigned *__restrict__ totals) {
+                                                                  unsigned *__restrict__ totals,
+                                                                  unsigned *__restrict__ counts0,
+                                                                  size_t tiles_per_chunk, size_t num_chunks) {
+  // One read of the keys: digit totals of EVERY pass and, because the workgroups walk the input chunk by chunk,
+  // the per-chunk digit counts of pass 0 as well (counts0[digit][chunk]) — the first pass then needs no
+  // rs_chunk_hist of its own.
   constexpr int kRadix = 1 << BITS;
   constexpr int kPasses = 32 / BITS;
-  __shared__ unsigned s_hist[kPasses * kRadix];
+  __shared__ unsigned s_hist[kPasses * kRadix];  // [0][*] is filled from the chunk counts
+  __shared__ unsigned s_chunk[kRadix];
   for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) s_hist[i] = 0;
-  __syncthreads();
-  const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
-  const size_t n4 = n / 4;
-  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kRsThreads + threadIdx.x; i < n4; i += stride) {
-    const u32x4 v = k4[i];
-    const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
+  const size_t chunk_keys = tiles_per_chunk * kRsTile;
+  for (size_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
+    for (int i = threadIdx.x; i < kRadix; i += kRsThreads) s_chunk[i] = 0;
+    __syncthreads();
+    const size_t lo = chunk * chunk_keys;
+    size_t hi = lo + chunk_keys;
+    hi = hi < n ? hi : n;
+    const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
+    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
+    for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
+      const u32x4 v = k4[i];
+      const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
 #pragma unroll
-    for (int p = 0; p < kPasses; ++p) {
-      // a digit that is the same in the whole wave (the upper bytes of small keys: the reference's
-      // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
-      const unsigned d0 = (k[0] >> (p * BITS)) & (kRadix - 1);
-      const unsigned first = __builtin_amdgcn_readfirstlane(d0);
-      const bool same = ((k[0] >> (p * BITS)) & (kRadix - 1)) == first && ((k[1] >> (p * BITS)) & (kRadix - 1)) == first &&
-                        ((k[2] >> (p * BITS)) & (kRadix - 1)) == first && ((k[3] >> (p * BITS)) & (kRadix - 1)) == first;
-      const unsigned long long active = __ballot(true);
-      if (__ballot(same) == active) {
-        if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
-          atomicAdd(&s_hist[p * kRadix + first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
-      } else {
+      for (int p = 0; p < kPasses; ++p) {
+        unsigned *hist = p == 0 ? s_chunk : s_hist + p * kRadix;
+        // a digit that is the same in the whole wave (the upper bytes of small keys: the reference's
+        // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
+        const unsigned d0 = (k[0] >> (p * BITS)) & (kRadix - 1);
+        const unsigned first = __builtin_amdgcn_readfirstlane(d0);
+        const bool same = ((k[0] >> (p * BITS)) & (kRadix - 1)) == first && ((k[1] >> (p * BITS)) & (kRadix - 1)) == first &&
+                          ((k[2] >> (p * BITS)) & (kRadix - 1)) == first && ((k[3] >> (p * BITS)) & (kRadix - 1)) == first;
+        const unsigned long long active = __ballot(true);
+        if (__ballot(same) == active) {
+          if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
+            atomicAdd(&hist[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&s_hist[p * kRadix + ((k[c] >> (p * BITS)) & (kRadix - 1))], 1u);
+          for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * BITS)) & (kRadix - 1)], 1u);
+        }
       }
     }
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
-    const unsigned k = keys[n4 * 4 + threadIdx.x] ^ xor_mask;
+    for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
+      const unsigned k = keys[i] ^ xor_mask;
+      atomicAdd(&s_chunk[k & (kRadix - 1)], 1u);
 #pragma unroll
-    for (int p = 0; p < kPasses; ++p)
-      atomicAdd(&s_hist[p * kRadix + ((k >> (p * BITS)) & (kRadix - 1))], 1u);
+      for (int p = 1; p < kPasses; ++p) atomicAdd(&s_hist[p * kRadix + ((k >> (p * BITS)) & (kRadix - 1))], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
+      const unsigned c = s_chunk[d];
+      counts0[static_cast<size_t>(d) * num_chunks + chunk] = c;
+      s_hist[d] += c;  // thread d owns s_hist[0][d]
+    }
+    __syncthreads();
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) {
@@ -520,13 +540,15 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * 4;
   const unsigned hgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
-  hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hgrid), dim3(kRsThreads), 0, s, keys, n,
-                     xor_mask, totals);
+  const unsigned hist_grid = static_cast<unsigned>(g.chunks < cap ? g.chunks : cap);
+  hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n,
+                     xor_mask, totals, counts, g.tiles_per_chunk, g.chunks);
   hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
   const unsigned cgrid = static_cast<unsigned>(g.chunks);
   for (int p = 0; p < kPasses; ++p) {
-    hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
-                       hdr, counts, g.tiles_per_chunk, g.chunks);
+    if (p > 0)  // pass 0's chunk counts came with the up-front histogram
+      hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
+                         hdr, counts, g.tiles_per_chunk, g.chunks);
     hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
                        g.chunks);
     hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys, tmp, n, p,
