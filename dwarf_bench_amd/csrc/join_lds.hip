@@ -248,8 +248,12 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
     const unsigned pid = jl_pid_sel<RANK>(k, parts);
     const unsigned d = LEVEL == 0 ? pid >> arg : pid & arg;
     const size_t slot = s_base[d] + (p - s_excl[d]);
-    out_keys[slot] = k;
-    out_rids[slot] = s_rids[p];
+    if (out_rids) {  // two columns (the rank-level partition: its outputs go into an all-to-all as they are)
+      out_keys[slot] = k;
+      out_rids[slot] = s_rids[p];
+    } else {  // one array of (key, row id) pairs: one 8-byte store per row, a run of r rows is 8r contiguous bytes
+      reinterpret_cast<u32x2 *>(out_keys)[slot] = u32x2{k, s_rids[p]};
+    }
   }
   __syncthreads();  // LDS is reused by the next tile
 }
@@ -339,8 +343,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
                                                                  const unsigned long long *__restrict__ tile_starts,
                                                                  unsigned parts, unsigned k1, unsigned k2,
                                                                  unsigned long long *cursors1,
-                                                                 unsigned *__restrict__ out_keys,
-                                                                 unsigned *__restrict__ out_rids) {
+                                                                 u32x2 *__restrict__ out_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
   unsigned bucket;
   unsigned long long tile;
@@ -356,11 +359,19 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
     rid[j] = valid ? rids[idx] : 0u;
     dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
   }
-  jl_scatter_tile<1>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2, out_keys,
-                     out_rids, s_mem);
+  jl_scatter_tile<1>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
+                     reinterpret_cast<unsigned *>(out_pairs), nullptr, s_mem);
 }
 
 // ---- per-partition build in LDS --------------------------------------------------------------------
+// A partition's rows come either as two columns (the level-0 output, when one level suffices) or as (key, row id)
+// pairs (the level-1 output): prids == nullptr means pkeys points at pairs.
+__device__ __forceinline__ u32x2 jl_row(const unsigned *__restrict__ pkeys, const unsigned *__restrict__ prids,
+                                        size_t i) {
+  if (prids) return u32x2{pkeys[i], prids[i]};
+  return reinterpret_cast<const u32x2 *>(pkeys)[i];
+}
+
 __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
@@ -392,8 +403,9 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     c_slot[r] = kJlSubSlots;  // "no row"
     c_rid[r] = 0;
     if (i < hi) {
-      const unsigned key = pkeys[i];
-      c_rid[r] = prids[i];
+      const u32x2 row = jl_row(pkeys, prids, i);
+      const unsigned key = row.x;
+      c_rid[r] = row.y;
       unsigned s = fmix32(key) & kJlSubMask;
       unsigned tries = 0;
       while (true) {
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     }
   }
   for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-    const unsigned key = pkeys[i];
+    const unsigned key = jl_row(pkeys, prids, i).x;
     unsigned s = fmix32(key) & kJlSubMask;
     unsigned tries = 0;
     while (true) {
@@ -454,10 +466,11 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
   for (int r = 0; r < kJlCached; ++r)
     if (c_slot[r] < kJlSubSlots) ids[atomicAdd(&lp[c_slot[r]], 1u)] = c_rid[r];
   for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-    const unsigned key = pkeys[i];
+    const u32x2 row = jl_row(pkeys, prids, i);
+    const unsigned key = row.x;
     unsigned s = fmix32(key) & kJlSubMask;
     for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
-    if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = prids[i];
+    if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
   }
   __syncthreads();
   // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot i's
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__
 // duplicate build key keeps the first claimer's payload: keys are unique by contract, join/join.cpp:13-16), the
 // sub-table goes out as 8-byte slots {key, payload}.  Probe: one 8-byte gather per step.
 __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsigned *__restrict__ pkeys,
-                                                                    const unsigned *__restrict__ pvals,
+                                                                    const unsigned *__restrict__ prids,
                                                                     const unsigned long long *__restrict__ starts,
                                                                     u32x2 *__restrict__ table, unsigned *status) {
   __shared__ unsigned lk[kJlSubSlots];
@@ -515,12 +528,13 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
   }
   __syncthreads();
   for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
-    const unsigned key = pkeys[i];
+    const u32x2 row = jl_row(pkeys, prids, i);
+    const unsigned key = row.x;
     unsigned s = fmix32(key) & kJlSubMask;
     for (unsigned tries = 0;; ++tries) {
       const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
       if (old == kEmptyKey) {
-        lv[s] = pvals[i];
+        lv[s] = row.y;
         break;
       }
       if (old == key) break;
@@ -583,7 +597,7 @@ inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
 
 namespace {
 struct JlPartitioned {
-  const unsigned *keys, *rids;             // partition-major (key, row id / payload) pairs
+  const unsigned *keys, *rids;             // partition-major rows: two columns, or rids == nullptr and keys -> pairs
   const unsigned long long *starts;        // parts + 1 offsets
   u32x2 *table;
   unsigned *status;
@@ -593,10 +607,11 @@ struct JlPartitioned {
 int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_t n, void *workspace, hipStream_t s,
                       const DeviceInfo &dev, const JlLayout &L, JlPartitioned *out) {
   char *base = static_cast<char *>(workspace);
-  unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);
-  unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);
-  unsigned *k_b = reinterpret_cast<unsigned *>(base + L.keys_b_off);
-  unsigned *r_b = reinterpret_cast<unsigned *>(base + L.rids_b_off);
+  unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);  // level-0 output: two columns (the level-1
+  unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);  // histogram reads the keys alone)
+  // level-1 output: (key, row id) pairs in the adjacent "keys b" + "row ids b" regions — one 8-byte store per row
+  // makes a run of r rows 8r contiguous bytes instead of two runs of 4r (scatter 330 -> 254 us at 2^26 rows)
+  u32x2 *rows_b = reinterpret_cast<u32x2 *>(base + L.keys_b_off);
   unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + L.meta_off);
   // meta: counts0g[G*k1] | cursors0g[G*k1] | starts0[k1+1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
   unsigned long long *counts0 = meta;
@@ -634,9 +649,9 @@ int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(L.k1), dim3(kJlThreads), 0, s, counts1, starts0, L.k1, L.k2, starts1,
                        cursors1);
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
-                       L.parts, L.k1, L.k2, cursors1, k_b, r_b);
-    out->keys = k_b;
-    out->rids = r_b;
+                       L.parts, L.k1, L.k2, cursors1, rows_b);
+    out->keys = reinterpret_cast<const unsigned *>(rows_b);
+    out->rids = nullptr;
     out->starts = starts1;
   }
   out->table = reinterpret_cast<u32x2 *>(base + L.table_off);
