@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X dwarf backend.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dwarf scan|sort|groupby|join|all] [--no-cpu] [--no-pjoin]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dwarf scan|sort|groupby|join|all] [--no-cpu] [--no-pjoin] [--no-sweep]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM.
 N = 1 (default): the configuration BASELINE.json's metric is quoted on — TwoPassScan (stream compaction
@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--dwarf", default="all", choices=["all", "scan", "sort", "groupby", "join"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pjoin", action="store_true", help="skip the single-GPU 2^30 x 2^30 join (profiling passes)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the scan selectivity sweep (counter passes: keeps "
+                    "every scan dispatch at the headline selectivity)")
     args = ap.parse_args()
 
     rank, world, local = _dist_env()
@@ -380,7 +382,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_scan(scan["src"], 5)
         else:
             out["cpu_baseline"] = None
-    sweep = scan_selectivity_sweep(scan["src"], scan["plan"], scan["rows"]) if (rank == 0 and n_gpus == 1) else None
+    sweep = (scan_selectivity_sweep(scan["src"], scan["plan"], scan["rows"])
+             if (rank == 0 and n_gpus == 1 and not args.no_sweep) else None)
     del scan["src"], scan["plan"]
     torch.cuda.empty_cache()
 

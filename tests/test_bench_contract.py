@@ -21,7 +21,9 @@ def test_committed_bench_line_has_the_contract_fields():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(roof["achieved"] - roof["algorithmic_bytes"] / roof["kernel_us_avg"] / 1e3) < 1e-6 * roof["achieved"]
-    assert roof["traffic"] is None or roof["traffic"] >= 0.99 * roof["algorithmic_bytes"]
+    assert roof["traffic"] is None or 0.99 * roof["algorithmic_bytes"] <= roof["traffic"] <= 1.05 * roof["algorithmic_bytes"]
+    committed = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())["scan"]["hbm_bytes_per_launch"]
+    assert 0.99 * roof["algorithmic_bytes"] <= committed <= 1.05 * roof["algorithmic_bytes"]  # no re-reads
     # value = rows / wall time of a step
     assert abs(line["value"] - line["config"]["rows"] / (line["ms_per_step"] * 1e3)) < 1e-6 * line["value"]
     cpu = line["cpu_baseline"]

@@ -12,9 +12,9 @@ cd /tmp
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o kt -- python3 "$repo/bench.py" --steps 20 --warmup 3 --no-cpu > "$out/bench_under_kt.log" 2>&1
 echo "[profile] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin > "$out/bench_under_pmc_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep > "$out/bench_under_pmc_fetch.log" 2>&1
 echo "[profile] FETCH_SIZE done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin > "$out/bench_under_pmc_write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep > "$out/bench_under_pmc_write.log" 2>&1
 echo "[profile] WRITE_SIZE done"
 cd "$repo"
 python3 tools/profile_summary.py "$out" "$tag"

@@ -65,7 +65,7 @@ def main():
                          "FETCH_SIZE_KiB_mean": sum(f) / len(f) if f else None, "FETCH_SIZE_KiB_max": max(f) if f else None,
                          "WRITE_SIZE_KiB_mean": sum(w) / len(w) if w else None, "WRITE_SIZE_KiB_max": max(w) if w else None}
     (prof / f"{tag}_pmc.json").write_text(json.dumps({
-        "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-pjoin ; same with "
+        "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep ; same with "
                    "--pmc WRITE_SIZE (separate passes, tools/profile_r01.sh)", "kernels": per_kernel}, indent=1))
 
     traffic = {"_comment": "HBM bytes per call from rocprofv3 --pmc passes (profiles/%s_pmc.json); counters are KiB; "
