@@ -319,6 +319,9 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = _dist_env()
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer sharing between the ranks
+    # fails with hipIpcGetMemHandle: invalid argument (already exported on the boxes; kept for any other launcher)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("DBENCH_FAULT_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DBENCH_FAULT_DUMP"]), exit=True)
