@@ -110,22 +110,38 @@ __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long l
                                                            unsigned long long *starts, unsigned long long *tile_starts,
                                                            unsigned long long *totals_out) {
   __shared__ unsigned long long s_tot[1024], s_start[1025], s_tstart[1025];
-  const unsigned b = threadIdx.x;
+  __shared__ unsigned long long s_wrow[16], s_wtile[16];
+  const unsigned b = threadIdx.x, lane = b & (kWave - 1), wave = b / kWave;
   unsigned long long tot = 0;
   if (b < k1)
     for (unsigned g = 0; g < kJlGroups; ++g) tot += counts_g[static_cast<size_t>(g) * k1 + b];
   s_tot[b] = tot;
-  __syncthreads();
-  if (b == 0) {
-    unsigned long long run = 0, trun = 0;
-    for (unsigned i = 0; i < k1; ++i) {
-      s_start[i] = run;
-      s_tstart[i] = trun;
-      run += s_tot[i];
-      trun += (s_tot[i] + kJlTile - 1) / kJlTile;
+  // exclusive prefix over the buckets of rows and of 4096-row tiles: wave scans + a 16-entry pass
+  const unsigned long long tl = b < k1 ? (tot + kJlTile - 1) / kJlTile : 0ull;
+  unsigned long long ir = tot, it = tl;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned long long pr = __shfl_up(ir, off, kWave), pt = __shfl_up(it, off, kWave);
+    if (lane >= static_cast<unsigned>(off)) {
+      ir += pr;
+      it += pt;
     }
-    s_start[k1] = run;
-    s_tstart[k1] = trun;
+  }
+  if (lane == kWave - 1) {
+    s_wrow[wave] = ir;
+    s_wtile[wave] = it;
+  }
+  __syncthreads();
+  unsigned long long base_r = 0, base_t = 0;
+  for (unsigned w = 0; w < wave; ++w) {
+    base_r += s_wrow[w];
+    base_t += s_wtile[w];
+  }
+  s_start[b] = base_r + ir - tot;
+  s_tstart[b] = base_t + it - tl;
+  if (b == 1023) {
+    s_start[1024] = base_r + ir;
+    s_tstart[1024] = base_t + it;
   }
   __syncthreads();
   if (b < k1) {
