@@ -53,6 +53,7 @@ constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
 constexpr int kRsMaxPasses = 8;
 constexpr int kRsMaxRadix = 256;
 constexpr size_t kRsTargetChunks = 2048;         // chunks per pass (>= 8 per CU for balance)
+constexpr size_t kRsFusedScanChunks = 32;        // up to this many chunks the scatter sums its own prefix (2^16 keys: 89 -> 80 us; at 128 chunks it costs 17 us)
 
 struct RsPass {
   unsigned skip;        // digit constant over the input: the pass's kernels return immediately
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
                                                                          int pass, unsigned xor_mask,
                                                                          const RsHeader *hdr,
                                                                          const unsigned *__restrict__ offsets,
+                                                                         const unsigned *__restrict__ bases,
                                                                          size_t tiles_per_chunk, size_t num_chunks) {
+  // bases != nullptr: `offsets` still holds the raw per-chunk counts and this kernel sums its own prefix (few
+  // chunks: the separate scan kernel would only add a dependent launch, ~5 us each at small sizes)
   constexpr int kRadix = 1 << BITS;
   __shared__ unsigned s_cnt[kRsWaves][kRadix];  // per-wave digit counts, then wave-exclusive offsets
   __shared__ unsigned s_dexcl[kRadix];          // tile-local exclusive offset of each digit
@@ -389,7 +393,16 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   size_t last_tile = first_tile + tiles_per_chunk;
   last_tile = last_tile < total_tiles ? last_tile : total_tiles;
   // digit owners keep the chunk's running global offset of their digit in a register
-  unsigned running = tid < kRadix ? offsets[static_cast<size_t>(tid) * num_chunks + chunk] : 0u;
+  unsigned running = 0;
+  if (tid < kRadix) {
+    if (bases) {
+      running = bases[pass * kRsMaxRadix + tid];
+      const unsigned *row = offsets + static_cast<size_t>(tid) * num_chunks;
+      for (size_t c = 0; c < chunk; ++c) running += row[c];
+    } else {
+      running = offsets[static_cast<size_t>(tid) * num_chunks + chunk];
+    }
+  }
 
   // (prefetching the next tile's keys into a second register set was measured: it needs 3 waves/SIMD
   //  instead of 4 to avoid spills and came out 7 % slower at 2^24 keys)
@@ -545,14 +558,17 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
                      xor_mask, totals, counts, g.tiles_per_chunk, g.chunks);
   hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
   const unsigned cgrid = static_cast<unsigned>(g.chunks);
+  const bool fused_scan = g.chunks <= kRsFusedScanChunks;
   for (int p = 0; p < kPasses; ++p) {
     if (p > 0)  // pass 0's chunk counts came with the up-front histogram
       hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
                          hdr, counts, g.tiles_per_chunk, g.chunks);
-    hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
-                       g.chunks);
+    if (!fused_scan)
+      hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
+                         g.chunks);
     hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys, tmp, n, p,
-                       xor_mask, hdr, counts, g.tiles_per_chunk, g.chunks);
+                       xor_mask, hdr, counts, fused_scan ? bases : static_cast<const unsigned *>(nullptr), g.tiles_per_chunk,
+                       g.chunks);
   }
   hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
   return launch_status();
