@@ -366,7 +366,7 @@ def main():
                    "parallelism": "single GPU" if n_gpus == 1 else f"{n_gpus} independent replicas (scan does not shard)"},
         "roofline": {"bound": "hbm", "achieved": scan["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": scan["achieved_gbs"] / HBM_PEAK_GBS, "traffic": _traffic_for("scan"),
-                     "kernel": "scan_chunk_kernel (+ memset, scan_move_kernel in the same event bracket)",
+                     "kernel": "scan_chunk_kernel (+ scan_move_kernel in the same event bracket)",
                      "kernel_us_avg": scan["kernel_us_avg"], "algorithmic_bytes": scan["algorithmic_bytes"]},
     }
 

@@ -168,13 +168,16 @@ __global__ __launch_bounds__(kScanSmallWaves *kWave) void copy_if_lt_kernel(
 // streaming rate however it is pipelined (immediate, deferred by one or two tiles through an LDS
 // ring, replicated granules: all between 255 and 340 us at 2^28 against 160 us for the bare stream).
 // So the large path removes the dependency instead of hiding it:
-//   scan_chunk_kernel  chunks (1 MiB for large inputs) are handed out by ticket.  A 16-wave workgroup streams its chunk
+//   scan_chunk_kernel  chunks (1 MiB for large inputs) are dealt by blockIdx — nothing here waits on another
+//                      workgroup, so no ticket and no zeroed header are needed: the call is two launches.
+//                      A 16-wave workgroup streams its chunk
 //                      tile by tile (128 KiB, double-buffered registers, next tile's loads issued
 //                      right after the count, a barrier that does not drain vmcnt), ranks matches
 //                      with ballots/mbcnt and writes them to the chunk's own slot of a staging buffer at
 //                      chunk-local offsets; one count per chunk.
 //   scan_move_kernel   one workgroup per chunk: prefix of the chunk counts (<= 4 KiB, read from L2),
-//                      then a coalesced copy staging -> out at the global offset.
+//                      then a coalesced copy staging -> out at the global offset; writes out_size and the
+//                      (always clean) status word.
 // HBM bytes: 4n + 4*matches (stream) + 8*matches (move); at the reference's selectivity (4e-4) the
 // move is ~0.1 % of the traffic.  Needs an n-element staging buffer in the workspace.
 // =================================================================================================
@@ -229,20 +232,18 @@ __device__ __forceinline__ unsigned chunk_step(i32x4 (&cur)[kScanVpt], i32x4 (&n
 template <bool kAligned, bool kNontemporal>
 __global__ __launch_bounds__(kChThreads) void scan_chunk_kernel(const int *__restrict__ src, size_t n,
                                                                 int filter, int *__restrict__ staging,
-                                                                unsigned *__restrict__ counts,
-                                                                ScanWs *ws, size_t num_chunks,
+                                                                unsigned *__restrict__ counts, size_t num_chunks,
                                                                 unsigned tiles_per_chunk) {
   // two slots alternate with the tile parity: one barrier per tile is enough
   __shared__ unsigned s_wave_total[2][kChWaves];
-  __shared__ unsigned long long s_chunk;
   const unsigned lane = threadIdx.x & (kWave - 1);
   const unsigned wave = threadIdx.x / kWave;
 
-  while (true) {
-    if (threadIdx.x == 0) s_chunk = take_tickets(ws, 1);
-    __syncthreads();
-    const size_t chunk = s_chunk;
-    if (chunk >= num_chunks) return;  // uniform
+  // Chunks are dealt by blockIdx, not by ticket: this kernel never waits on another workgroup, so residency does
+  // not matter for progress, and without a ticket counter the call needs no zeroed header — one dependent launch
+  // (the fill) less in front of the stream.
+  for (size_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
+    __syncthreads();  // the previous chunk's last tile may still be reading the s_wave_total slot tile 0 writes
     const size_t chunk_elems = static_cast<size_t>(tiles_per_chunk) * kChTile;
     const size_t first_tile = chunk * tiles_per_chunk;
     const size_t elems = n - chunk * chunk_elems < chunk_elems ? n - chunk * chunk_elems : chunk_elems;
@@ -261,7 +262,6 @@ __global__ __launch_bounds__(kChThreads) void scan_chunk_kernel(const int *__res
                                                    wave, lane);
     }
     if (threadIdx.x == 0) counts[chunk] = running;
-    // s_chunk is rewritten only after every wave has passed this chunk's tile barriers
   }
 }
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
                                                         const unsigned *__restrict__ counts,
                                                         int *__restrict__ out,
                                                         unsigned long long *__restrict__ out_size,
-                                                        size_t num_chunks, size_t chunk_elems) {
+                                                        size_t num_chunks, size_t chunk_elems, ScanWs *ws) {
   __shared__ unsigned long long s_part[256 / kWave];
   const size_t chunk = blockIdx.x;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -285,7 +285,10 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
   const int *src = staging + chunk * chunk_elems;
   int *dst = out + prefix;
   for (unsigned j = tid; j < m; j += 256) dst[j] = src[j];
-  if (chunk == num_chunks - 1 && tid == 0) *out_size = prefix + m;
+  if (chunk == num_chunks - 1 && tid == 0) {
+    *out_size = prefix + m;
+    ws->status = DBHIP_DEV_OK;  // nothing on this path can fail on the device; the header is not cleared up front
+  }
 }
 
 inline int env_int(const char *name, int lo, int hi, int dflt) {
@@ -323,14 +326,12 @@ int launch_chunked(const int *src, size_t n, int filter, int *out, unsigned long
   ScanWs *ws = reinterpret_cast<ScanWs *>(base);
   unsigned *counts = reinterpret_cast<unsigned *>(base + L.counts_off);
   int *staging = reinterpret_cast<int *>(base + L.staging_off);
-  hipError_t e = fill_async(workspace, 0, kWsHeader, s);  // status word + ticket counter
-  if (e != hipSuccess) return static_cast<int>(e);
   const size_t cap = static_cast<size_t>(dev.cus);  // one 16-wave workgroup per CU
   const unsigned grid = static_cast<unsigned>(L.chunks < cap ? L.chunks : cap);
   hipLaunchKernelGGL((scan_chunk_kernel<kAligned, kNontemporal>), dim3(grid), dim3(kChThreads), 0, s, src, n,
-                     filter, staging, counts, ws, L.chunks, L.tiles_per_chunk);
+                     filter, staging, counts, L.chunks, L.tiles_per_chunk);
   hipLaunchKernelGGL(scan_move_kernel, dim3(static_cast<unsigned>(L.chunks)), dim3(256), 0, s, staging,
-                     counts, out, osz, L.chunks, L.chunk_elems);
+                     counts, out, osz, L.chunks, L.chunk_elems, ws);
   return launch_status();
 }
 
