@@ -52,10 +52,12 @@ def main():
     prof = ROOT / "profiles"
     prof.mkdir(exist_ok=True)
     stats = sorted((raw / "kt").rglob("*kernel_stats.csv"))
-    if stats:
-        shutil.copy(stats[0], prof / f"{tag}_bench_kernel_stats.csv")
     fetch = read_pmc(raw / "pmc_fetch", "FETCH_SIZE")
     write = read_pmc(raw / "pmc_write", "WRITE_SIZE")
+    if not stats or not fetch or not write:
+        sys.exit(f"{raw}: incomplete rocprofv3 output (kernel stats: {bool(stats)}, FETCH_SIZE: {bool(fetch)}, "
+                 f"WRITE_SIZE: {bool(write)}) — profiles/ left untouched")
+    shutil.copy(stats[0], prof / f"{tag}_bench_kernel_stats.csv")
     per_kernel = {}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("dbhip::"):
