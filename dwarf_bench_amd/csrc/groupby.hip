@@ -25,7 +25,12 @@ namespace {
 
 constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table
 constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table is large
-constexpr int kGbVecPerIter = 2;        // uint4 key + uint4 val loads in flight per lane per step
+#ifndef DBHIP_GB_VEC
+#define DBHIP_GB_VEC 2
+#endif
+constexpr int kGbVecPerIter = DBHIP_GB_VEC;  // uint4 key + uint4 val loads in flight per lane per step (4 or 8: a few
+                                             // us either way for one key range, 123 -> 146 us for two: the partner
+                                             // workgroups drift apart and lose the shared read)
 
 struct GbHeader {
   unsigned status;
