@@ -303,7 +303,9 @@ inline bool scan_nontemporal() {
 }
 // elements from which the chunked two-kernel path is used
 inline size_t scan_big_threshold() {
-  static const int lg = env_int("DBHIP_SCAN_BIG_LOG2", 10, 40, 22);
+  // 2^18: since the chunked path became two launches it is level with or ahead of the look-back kernel from here
+  // up (2^21 elements: 18.9 -> 15.3 us)
+  static const int lg = env_int("DBHIP_SCAN_BIG_LOG2", 10, 40, 18);
   return static_cast<size_t>(1) << lg;
 }
 

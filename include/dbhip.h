@@ -78,7 +78,7 @@ int dbhip_gen_unique_sorted_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t
 
 /* ---- dwarf 1: scan / stream compaction --------------------------------------------------------
  * out[0..*out_size) = [x in src : x < filter_value] in source order (stable), *out_size = count.
- * src is read ONCE: below 2^22 elements a single-pass kernel with decoupled look-back; above, a chunked
+ * src is read ONCE: below 2^18 elements a single-pass kernel with decoupled look-back; above, a chunked
  * kernel stages each chunk's matches in the workspace (which therefore holds n elements) and a second
  * small kernel moves them to their final offsets.  `out` needs room for n elements in the worst case.
  * out_size is a DEVICE pointer to one uint64.                                                    */

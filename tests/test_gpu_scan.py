@@ -86,10 +86,10 @@ def test_full_size_properties_2_28():
     assert np.array_equal(ops.copy_if_lt(src[:m], 5).cpu().numpy(), po.copy_if_lt(src[:m].cpu().numpy(), 5))
 
 
-def test_stress_under_uneven_load():
-    """Look-back hand-offs under uneven load: varying selectivity per region + a second stream hammering HBM."""
+@pytest.mark.parametrize("n", [(1 << 24) + 777, 250007, 77777])  # chunked path, look-back path (n < 2^18)
+def test_stress_under_uneven_load(n):
+    """Hand-offs under uneven load: varying selectivity per region + a second stream hammering HBM."""
     from dwarf_bench_amd import ops
-    n = (1 << 24) + 777
     host = po.gen_uniform_u32(n, 3, 1, 10000).astype(np.int32)
     host[: n // 3] = 1           # dense matches up front
     host[n // 3: n // 2] = 9999  # none
