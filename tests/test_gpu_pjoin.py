@@ -99,11 +99,12 @@ def _worker(rank, world, port, n, key_hi, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,key_hi", [(3000, 2000), (50001, 10000)])
-def test_two_ranks_on_one_gpu(n, key_hi):
+@pytest.mark.parametrize("world,n,key_hi", [(2, 3000, 2000), (2, 50001, 10000), (3, 400003, 2**32 - 2), (4, 1 << 20, (1 << 20) - 1)])
+def test_ranks_sharing_one_gpu(world, n, key_hi):
+    """the whole partitioned join (HIP backend) with several ranks on the box's one GPU; 3 and 4 ranks, ragged shards,
+    and shards large enough for the LDS-partitioned local join"""
     import torch.multiprocessing as mp
     from tests.pjoin_testlib import check_global
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
