@@ -7,48 +7,29 @@
 //
 //   * ONE pass over src.  Every wave reads 2048 contiguous elements of a tile with eight
 //     16-byte-per-lane non-temporal loads (each wave instruction = 1 KiB contiguous), keeps them in
-//     registers, counts, and emits the matches once the tile's global offset is known.
-//   * Tiles are handed out by a ticket counter (one returning atomic per tile), NOT by blockIdx: a
-//     tile index is only ever held by a workgroup that is running, so a look-back can never wait on
-//     a workgroup that is not resident (other kernels may share the GPU), and tiles start in ticket
-//     order, which keeps look-back distances short.
-//   * The offset comes from a decoupled look-back over one 8-byte {state, value} granule per tile
-//     (lookback.hpp): agent-scope relaxed atomics, flag and value in one store, no fences, nothing
-//     depends on workgroup->XCD placement or dispatch order.
+//     registers, counts, and writes its matches at an offset inside the chunk's staging slot.
 //   * In-wave ranks come from the compare masks themselves: v_cmp -> 64-bit ballot in SGPRs,
 //     s_bcnt1 for totals, v_mbcnt_lo/hi for the lane-exclusive prefix.
+//   * No workgroup ever waits on another one (see below): no tickets, no look-back, no spin, nothing to time
+//     out; every call is two launches whatever the size.
 //
-// Small inputs use the single-pass look-back kernel; large inputs the chunked two-kernel path below,
-// which needs no look-back at all.
-//
-// Algorithmic HBM bytes: 4*n read + 4*out_size written (+ ~24 B of granule/ticket traffic per tile).
+// Algorithmic HBM bytes: 4*n read + 4*out_size written.
 #include <climits>
 
 #include "dbhip_common.hpp"
-#include "lookback.hpp"
 
 namespace dbhip {
 namespace {
 
 constexpr int kScanVpt = 8;                           // 16-byte loads per lane per tile
 constexpr int kScanWaveElems = kWave * kScanVpt * 4;  // 2048 contiguous elements per wave
-constexpr int kScanSmallWaves = 4;                    // 32 KiB tiles
-constexpr int kScanSmallTile = kScanWaveElems * kScanSmallWaves;
 
 struct ScanWs {
-  unsigned status;  // DBHIP_DEV_* bits
-  unsigned pad0;
-  unsigned long long ticket;  // next tile index to hand out
-  unsigned pad[60];
-  // followed by one 8-byte granule per tile
+  unsigned status;  // DBHIP_DEV_* bits (this dwarf has no device-side failure: always DBHIP_DEV_OK after a call)
+  unsigned pad[63];
 };
 static_assert(sizeof(ScanWs) == kWsHeader, "workspace header size");
 
-__device__ __forceinline__ unsigned long long take_tickets(ScanWs *ws, unsigned long long count) {
-  return __hip_atomic_fetch_add(&ws->ticket, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// loads the 2048 elements of wave `wave` of tile `tile` (tile size = kScanWaveElems * WAVES)
 template <int WAVES, bool kAligned, bool kNontemporal>
 __device__ __forceinline__ void load_wave_tile(i32x4 (&v)[kScanVpt], const int *__restrict__ src,
                                                size_t n, size_t tile, unsigned wave, unsigned lane) {
@@ -107,67 +88,19 @@ __device__ __forceinline__ void emit_wave_matches(const i32x4 (&v)[kScanVpt], in
 // =================================================================================================
 // Small inputs: one tile at a time per workgroup, immediate look-back, direct writes.
 // =================================================================================================
-template <bool kAligned, bool kNontemporal>
-__global__ __launch_bounds__(kScanSmallWaves *kWave) void copy_if_lt_kernel(
-    const int *__restrict__ src, size_t n, int filter, int *__restrict__ out,
-    unsigned long long *__restrict__ out_size, ScanWs *ws, size_t num_tiles) {
-  __shared__ unsigned s_wave_total[kScanSmallWaves];
-  __shared__ unsigned long long s_tile_excl;
-  __shared__ unsigned long long s_tile;
-
-  unsigned long long *granules = reinterpret_cast<unsigned long long *>(ws + 1);
-  const unsigned lane = threadIdx.x & (kWave - 1);
-  const unsigned wave = threadIdx.x / kWave;
-
-  while (true) {
-    if (threadIdx.x == 0) s_tile = take_tickets(ws, 1);
-    __syncthreads();
-    const size_t tile = s_tile;
-    if (tile >= num_tiles) return;  // uniform
-
-    i32x4 v[kScanVpt];
-    load_wave_tile<kScanSmallWaves, kAligned, kNontemporal>(v, src, n, tile, wave, lane);
-    const unsigned wave_total = count_wave_matches(v, filter);
-    if (lane == 0) s_wave_total[wave] = wave_total;
-    __syncthreads();
-
-    unsigned wave_excl = 0, tile_total = 0;
-#pragma unroll
-    for (int w = 0; w < kScanSmallWaves; ++w) {
-      const unsigned t = s_wave_total[w];
-      wave_excl += w < static_cast<int>(wave) ? t : 0u;
-      tile_total += t;
-    }
-    if (wave == 0) {
-      unsigned long long excl = 0;
-      if (tile == 0) {
-        if (lane == 0) st_agent(granules, kLb64Inclusive | tile_total);
-      } else {
-        if (lane == 0) st_agent(granules + tile, kLb64Aggregate | tile_total);
-        excl = lookback_wave64(granules, tile, lane, &ws->status);
-        if (lane == 0) st_agent(granules + tile, kLb64Inclusive | ((excl + tile_total) & kLb64Value));
-      }
-      if (lane == 0) {
-        s_tile_excl = excl;
-        if (tile == num_tiles - 1) *out_size = excl + tile_total;
-      }
-    }
-    __syncthreads();
-    if (wave_total != 0) emit_wave_matches(v, filter, out + s_tile_excl + wave_excl);
-    // s_tile / s_wave_total / s_tile_excl are rewritten only after the next loop-top barrier
-  }
-}
-
 // =================================================================================================
-// Large inputs: chunked path, two kernels, NO communication between workgroups while streaming.
+// Chunked path, two kernels, NO communication between workgroups while streaming.
 //
+// History: the first version was a single-pass kernel with decoupled look-back (tickets, 8-byte {state, value}
+// granules, bounded spins).  It survives in join.hip's slot scan; here it lost at every size:
 // Measured on MI355X (profiles/): with all 256 CUs streaming, ~30 MiB of loads are in flight and any
 // read that must come from memory — a look-back poll included — takes 3.5-4.5 us, as long as a CU
 // needs for a whole 128 KiB tile, and 256 CUs polling the same few KiB of granules overload the
 // HBM channels that hold them.  A single-pass look-back therefore tops out near 50 % of the
 // streaming rate however it is pipelined (immediate, deferred by one or two tiles through an LDS
 // ring, replicated granules: all between 255 and 340 us at 2^28 against 160 us for the bare stream).
-// So the large path removes the dependency instead of hiding it:
+// and at small sizes the two launches below are level with its fill + kernel (2^10..2^18 elements: 12.9-14.2 us
+// against 14.3-16.1 us).  So the dependency is removed instead of hidden:
 //   scan_chunk_kernel  chunks (1 MiB for large inputs) are dealt by blockIdx — nothing here waits on another
 //                      workgroup, so no ticket and no zeroed header are needed: the call is two launches.
 //                      A 16-wave workgroup streams its chunk
@@ -301,25 +234,6 @@ inline bool scan_nontemporal() {
   static const int v = env_int("DBHIP_SCAN_NT", 0, 1, 1);
   return v != 0;
 }
-// elements from which the chunked two-kernel path is used
-inline size_t scan_big_threshold() {
-  // 2^18: since the chunked path became two launches it is level with or ahead of the look-back kernel from here
-  // up (2^21 elements: 18.9 -> 15.3 us)
-  static const int lg = env_int("DBHIP_SCAN_BIG_LOG2", 10, 40, 18);
-  return static_cast<size_t>(1) << lg;
-}
-
-template <bool kAligned, bool kNontemporal>
-int launch_small(const int *src, size_t n, int filter, int *out, unsigned long long *osz, ScanWs *ws,
-                 const DeviceInfo &dev, size_t tiles, hipStream_t s) {
-  // tickets make residency irrelevant for correctness: fill the chip
-  const size_t cap = static_cast<size_t>(dev.cus) * env_int("DBHIP_SCAN_BLOCKS_PER_CU", 1, 8, 6);
-  const unsigned grid = static_cast<unsigned>(tiles < cap ? tiles : cap);
-  hipLaunchKernelGGL((copy_if_lt_kernel<kAligned, kNontemporal>), dim3(grid),
-                     dim3(kScanSmallWaves * kWave), 0, s, src, n, filter, out, osz, ws, tiles);
-  return launch_status();
-}
-
 template <bool kAligned, bool kNontemporal>
 int launch_chunked(const int *src, size_t n, int filter, int *out, unsigned long long *osz, void *workspace,
                    const DeviceInfo &dev, hipStream_t s) {
@@ -343,11 +257,7 @@ int launch_chunked(const int *src, size_t n, int filter, int *out, unsigned long
 using namespace dbhip;
 
 extern "C" size_t dbhip_copy_if_lt_i32_workspace_bytes(size_t n) {
-  const size_t tiles = (n + kScanSmallTile - 1) / kScanSmallTile;
-  const size_t small_total = align_up(kWsHeader + (tiles ? tiles : 1) * sizeof(unsigned long long), kWsAlign);
-  if (n < scan_big_threshold()) return small_total;
-  const size_t big_total = chunk_layout(n).total;  // includes the n-element staging buffer
-  return big_total > small_total ? big_total : small_total;
+  return chunk_layout(n ? n : 1).total;  // header | counts[chunks] | staging[n]
 }
 
 extern "C" int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value,
@@ -367,18 +277,7 @@ extern "C" int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter
   }
   unsigned long long *osz = reinterpret_cast<unsigned long long *>(out_size);
   const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
-  const bool nt = scan_nontemporal();
-  if (n >= scan_big_threshold()) {
-    if (!aligned) return launch_chunked<false, false>(src, n, filter_value, out, osz, workspace, dev, s);
-    if (nt) return launch_chunked<true, true>(src, n, filter_value, out, osz, workspace, dev, s);
-    return launch_chunked<true, false>(src, n, filter_value, out, osz, workspace, dev, s);
-  }
-  const size_t tiles = (n + kScanSmallTile - 1) / kScanSmallTile;
-  // ticket counter, status word and granules must be zero before every launch
-  hipError_t e = fill_async(workspace, 0, align_up(kWsHeader + tiles * sizeof(unsigned long long), 16), s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  ScanWs *ws = static_cast<ScanWs *>(workspace);
-  if (!aligned) return launch_small<false, false>(src, n, filter_value, out, osz, ws, dev, tiles, s);
-  if (nt) return launch_small<true, true>(src, n, filter_value, out, osz, ws, dev, tiles, s);
-  return launch_small<true, false>(src, n, filter_value, out, osz, ws, dev, tiles, s);
+  if (!aligned) return launch_chunked<false, false>(src, n, filter_value, out, osz, workspace, dev, s);
+  if (scan_nontemporal()) return launch_chunked<true, true>(src, n, filter_value, out, osz, workspace, dev, s);
+  return launch_chunked<true, false>(src, n, filter_value, out, osz, workspace, dev, s);
 }

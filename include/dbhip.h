@@ -53,7 +53,7 @@ extern "C" {
 
 /* device-side status word values (dbhip_workspace_status) */
 #define DBHIP_DEV_OK 0u
-#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* a look-back wait gave up: result is invalid */
+#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* a look-back wait gave up: result is invalid (small-input join only) */
 #define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count */
 #define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
 
@@ -78,9 +78,8 @@ int dbhip_gen_unique_sorted_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t
 
 /* ---- dwarf 1: scan / stream compaction --------------------------------------------------------
  * out[0..*out_size) = [x in src : x < filter_value] in source order (stable), *out_size = count.
- * src is read ONCE: below 2^18 elements a single-pass kernel with decoupled look-back; above, a chunked
- * kernel stages each chunk's matches in the workspace (which therefore holds n elements) and a second
- * small kernel moves them to their final offsets.  `out` needs room for n elements in the worst case.
+ * src is read ONCE: a chunked kernel stages each chunk's matches in the workspace (which therefore holds n
+ * elements) and a second small kernel moves them to their final offsets; no workgroup waits on another.  `out` needs room for n elements in the worst case.
  * out_size is a DEVICE pointer to one uint64.                                                    */
 size_t dbhip_copy_if_lt_i32_workspace_bytes(size_t n);
 int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,

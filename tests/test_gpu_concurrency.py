@@ -17,7 +17,7 @@ def _dev(a):
 def test_dwarfs_on_concurrent_streams():
     from dwarf_bench_amd import ops
     rounds = 6
-    n_scan, n_sort, n_gb, groups, n_join = 3_000_000, 1 << 20, 1 << 21, 4096, 40_000  # small scan path, HBM-table join
+    n_scan, n_sort, n_gb, groups, n_join = 3_000_000, 1 << 20, 1 << 21, 4096, 40_000  # n_join: HBM-table path (look-back scan)
     src = po.gen_uniform_u32(n_scan, 1, 1, 10000).view(np.int32)
     keys = po.gen_uniform_u32(n_sort, 2, 0, 2**32 - 1)
     gk, gv = po.gen_uniform_u32(n_gb, 3, 0, groups - 1), po.gen_uniform_u32(n_gb, 4, 1, 10000)

@@ -86,7 +86,7 @@ def test_full_size_properties_2_28():
     assert np.array_equal(ops.copy_if_lt(src[:m], 5).cpu().numpy(), po.copy_if_lt(src[:m].cpu().numpy(), 5))
 
 
-@pytest.mark.parametrize("n", [(1 << 24) + 777, 250007, 77777])  # chunked path, look-back path (n < 2^18)
+@pytest.mark.parametrize("n", [(1 << 24) + 777, 250007, 77777])  # several chunks per workgroup, a few chunks, a single workgroup
 def test_stress_under_uneven_load(n):
     """Hand-offs under uneven load: varying selectivity per region + a second stream hammering HBM."""
     from dwarf_bench_amd import ops
