@@ -1,140 +1,36 @@
-// join.hip — dwarf 4: hash joins for gfx950 (single GPU, table in HBM).
+// join.hip — dwarf 4: entry points of the hash joins for gfx950, the small-input path of the unique-key join and the
+// bitmask-claimed table.
 //
 // 4a  one-to-many join, JoinOmnisci semantics (common/dpcpp/omnisci_hashtable.hpp:58-261 <-
-//     join/join_omnisci.cpp:74-88): open-addressing table of the DISTINCT build keys claimed with
-//     atomicCAS, per-slot match count, exclusive scan -> position, ids grouped by key, probe ->
-//     {offset into ids, count}.  Differences from the reference's five launches: insert and count are
-//     one kernel (the slot is known right after the CAS), the scan is a single-pass decoupled
-//     look-back over the slot counters, the id fill bumps pos[] itself (so there is no host-side
-//     zeroing of cnt, omnisci_hashtable.hpp:256-260), counters are 32-bit, and the slot hash is the
-//     Murmur3 finaliser masked to a power-of-two capacity instead of key % ht_size.  Table layout is
-//     not contractual: logical outputs are count per probe row + the set of ids.
-// 4b  unique-key payload join, Join semantics (join/join.cpp:60-104): CAS-claimed key slots with the
-//     payload stored next to them, probe writes (key, build_val, probe_val) at the probe row or the
+//     join/join_omnisci.cpp:74-88): distinct-key table, per-key match count, exclusive scan -> position, ids
+//     grouped by key, probe -> {offset into ids, count}.  Every size runs the radix-partitioned build with
+//     LDS-resident sub-tables of join_lds.hip.  (The first version kept the table in HBM — atomicCAS insert + count,
+//     a single-pass look-back scan over the slot counters, id fill: 19.3 ms at 2^26 x 2^26 against 2.9 ms, and not
+//     faster at any small size either, 2^8..2^16 rows: 34-46 us against 30-43 us — and was removed together with
+//     the look-back code, so nothing in this library spins on another workgroup any more.)
+//     Table layout is not contractual: logical outputs are count per probe row + the set of ids.
+// 4b  unique-key payload join, Join semantics (join/join.cpp:60-104): below 2^16 build rows a CAS-claimed
+//     {key, payload} table in HBM (four launches: 24-42 us where the partitioned build needs 31-49 us), above it the
+//     partitioned build of join_lds.hip; probe writes (key, build_val, probe_val) at the probe row or the
 //     0xFFFFFFFF sentinel.
 #include "dbhip_common.hpp"
 #include "join_common.hpp"
-#include "lookback.hpp"
 
 namespace dbhip {
 namespace {
 
 constexpr unsigned kEmpty = 0xFFFFFFFFu;
 constexpr int kJoinThreads = 256;
-constexpr int kScanVpt = 4;                                // uint4 per lane per tile
-constexpr int kScanTileElems = kJoinThreads * kScanVpt * 4;  // 4096 counters per tile
-
-struct JoinHeader {
-  unsigned status;
-  unsigned pad0;
-  unsigned long long capacity;  // slots (power of two)
-  unsigned long long n_build;
-  unsigned pad[58];
-};
-static_assert(sizeof(JoinHeader) == kWsHeader, "workspace header size");
-
 inline size_t join_capacity(size_t n_build) {
-  size_t cap = kScanTileElems;  // at least one full scan tile
+  size_t cap = 4096;
   while (cap < 2 * n_build) cap <<= 1;  // load factor <= 0.5 (reference: ht_size = 2 * distinct)
   return cap;
-}
-struct JoinLayout {
-  size_t cap, keys_off, cnt_off, pos_off, gran_off, total;
-};
-inline JoinLayout join_layout(size_t n_build) {
-  JoinLayout L;
-  L.cap = join_capacity(n_build);
-  L.keys_off = kWsHeader;
-  L.cnt_off = L.keys_off + L.cap * sizeof(unsigned);
-  L.pos_off = L.cnt_off + L.cap * sizeof(unsigned);
-  L.gran_off = L.pos_off + L.cap * sizeof(unsigned);
-  L.total = align_up(L.gran_off + (L.cap / kScanTileElems + 1) * sizeof(unsigned long long), kWsAlign);
-  return L;
 }
 
 inline unsigned grid_for(size_t n, const DeviceInfo &dev, int per_cu) {
   const size_t want = (n + kJoinThreads - 1) / kJoinThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
   return static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
-}
-
-// ---- 4a build: claim the key's slot (CAS) and count the row in the same visit -------------------
-__global__ __launch_bounds__(kJoinThreads) void join_insert_count_kernel(
-    const unsigned *__restrict__ build, size_t n, unsigned *keys, unsigned *cnt, unsigned mask,
-    JoinHeader *hdr) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride) {
-    const unsigned key = build[i];
-    unsigned s = fmix32(key) & mask;
-    unsigned tries = 0;
-    while (true) {
-      const unsigned old = atomicCAS(&keys[s], kEmpty, key);
-      if (old == kEmpty || old == key) {
-        atomicAdd(&cnt[s], 1u);
-        break;
-      }
-      s = (s + 1) & mask;
-      if (++tries > mask) {
-        atomicOr(&hdr->status, DBHIP_DEV_TABLE_FULL);
-        break;
-      }
-    }
-  }
-}
-
-// ---- single-pass exclusive scan of the slot counters: pos = exclusive_scan(cnt) -----------------
-__global__ __launch_bounds__(kJoinThreads) void join_scan_kernel(const unsigned *__restrict__ cnt,
-                                                                 unsigned *__restrict__ pos,
-                                                                 size_t n, JoinHeader *hdr,
-                                                                 unsigned long long *granules,
-                                                                 size_t num_tiles) {
-  __shared__ unsigned s_wsum[kJoinThreads / kWave];
-  __shared__ unsigned long long s_excl;
-  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  for (size_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    // n (the capacity) is a multiple of the tile size: every tile is full
-    const u32x4 *p = reinterpret_cast<const u32x4 *>(cnt + tile * kScanTileElems) + tid * kScanVpt;
-    u32x4 v[kScanVpt];
-    unsigned mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanVpt; ++k) {
-      v[k] = p[k];
-      mine += v[k].x + v[k].y + v[k].z + v[k].w;
-    }
-    const unsigned incl = wave_inclusive_scan(mine);
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned thread_excl = incl - mine, tile_total = 0;
-#pragma unroll
-    for (unsigned w = 0; w < kJoinThreads / kWave; ++w) {
-      thread_excl += w < wave ? s_wsum[w] : 0u;
-      tile_total += s_wsum[w];
-    }
-    if (wave == 0) {
-      unsigned long long excl = 0;
-      if (tile == 0) {
-        if (lane == 0) st_agent(granules, kLb64Inclusive | tile_total);
-      } else {
-        if (lane == 0) st_agent(granules + tile, kLb64Aggregate | tile_total);
-        excl = lookback_wave64(granules, tile, lane, &hdr->status);
-        if (lane == 0) st_agent(granules + tile, kLb64Inclusive | ((excl + tile_total) & kLb64Value));
-      }
-      if (lane == 0) s_excl = excl;
-    }
-    __syncthreads();
-    unsigned run = static_cast<unsigned>(s_excl) + thread_excl;
-    u32x4 *q = reinterpret_cast<u32x4 *>(pos + tile * kScanTileElems) + tid * kScanVpt;
-#pragma unroll
-    for (int k = 0; k < kScanVpt; ++k) {
-      u32x4 o;
-      o.x = run; run += v[k].x;
-      o.y = run; run += v[k].y;
-      o.z = run; run += v[k].z;
-      o.w = run; run += v[k].w;
-      q[k] = o;
-    }
-    __syncthreads();
-  }
 }
 
 // find the slot holding `key`, or the first empty slot of its probe chain
@@ -152,44 +48,6 @@ __device__ __forceinline__ unsigned find_slot(const unsigned *__restrict__ keys,
   }
   *found = false;
   return s;
-}
-
-// ---- 4a build: ids[pos[slot]++] = build row (pos ends up as the END offset of every slot) --------
-__global__ __launch_bounds__(kJoinThreads) void join_fill_ids_kernel(const unsigned *__restrict__ build,
-                                                                     size_t n,
-                                                                     const unsigned *__restrict__ row_ids,
-                                                                     const unsigned *__restrict__ keys,
-                                                                     unsigned *pos, unsigned mask,
-                                                                     unsigned *__restrict__ ids) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride) {
-    bool found;
-    const unsigned s = find_slot(keys, build[i], mask, &found);
-    if (found) ids[atomicAdd(&pos[s], 1u)] = row_ids ? row_ids[i] : static_cast<unsigned>(i);
-  }
-}
-
-// ---- 4a probe -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kJoinThreads) void join_probe_kernel(const unsigned *__restrict__ probe,
-                                                                  size_t n,
-                                                                  const unsigned *__restrict__ keys,
-                                                                  const unsigned *__restrict__ cnt,
-                                                                  const unsigned *__restrict__ pos_end,
-                                                                  unsigned mask,
-                                                                  unsigned *__restrict__ out_pos,
-                                                                  unsigned *__restrict__ out_cnt) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kJoinThreads + threadIdx.x; i < n; i += stride) {
-    bool found;
-    const unsigned s = find_slot(keys, probe[i], mask, &found);
-    unsigned c = 0, p = 0;
-    if (found) {
-      c = cnt[s];
-      p = pos_end[s] - c;
-    }
-    out_pos[i] = p;
-    out_cnt[i] = c;
-  }
 }
 
 // ---- 4b unique-key payload join -------------------------------------------------------------------
@@ -247,49 +105,18 @@ __global__ __launch_bounds__(kJoinThreads) void ujoin_probe_kernel(
 
 using namespace dbhip;
 
-extern "C" size_t dbhip_join_workspace_bytes(size_t n_build) {
-  return jl_use(n_build) ? jl_layout(n_build).total : join_layout(n_build).total;
-}
+extern "C" size_t dbhip_join_workspace_bytes(size_t n_build) { return jl_layout(n_build).total; }
 
 namespace {
 // shared by dbhip_join_build_u32 (row ids = 0..n-1) and dbhip_join_build_pairs_u32 (caller's row ids)
 int join_build_impl(const uint32_t *build_keys, const uint32_t *row_ids, size_t n_build, uint32_t *ids,
                     void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (n_build && (!build_keys || !ids)) return DBHIP_EINVAL;
-  if (n_build >= 0x7FFFFFFFull) return DBHIP_EINVAL;  // 32-bit ids / positions
+  if (n_build > kJlMaxRows) return DBHIP_EINVAL;  // 32-bit ids / positions, 2^20 partitions of 2048 rows
   if (!ws_ok(workspace, workspace_bytes, dbhip_join_workspace_bytes(n_build))) return DBHIP_EWORKSPACE;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
-  hipStream_t s = as_stream(stream);
-  if (jl_use(n_build))  // large build sides: radix-partitioned, LDS-resident sub-tables (join_lds.hip)
-    return join_lds_build(build_keys, row_ids, n_build, ids, workspace, s, dev);
-  const JoinLayout L = join_layout(n_build);
-  char *base = static_cast<char *>(workspace);
-  JoinHeader *hdr = reinterpret_cast<JoinHeader *>(base);
-  unsigned *keys = reinterpret_cast<unsigned *>(base + L.keys_off);
-  unsigned *cnt = reinterpret_cast<unsigned *>(base + L.cnt_off);
-  unsigned *pos = reinterpret_cast<unsigned *>(base + L.pos_off);
-  unsigned long long *gran = reinterpret_cast<unsigned long long *>(base + L.gran_off);
-  const unsigned mask = static_cast<unsigned>(L.cap - 1);
-
-  hipError_t e = fill_async(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = fill_async(keys, 0xFF, L.cap * sizeof(unsigned), s);
-  if (e == hipSuccess) e = fill_async(cnt, 0, L.cap * sizeof(unsigned), s);
-  if (e == hipSuccess) e = fill_async(gran, 0, L.total - L.gran_off, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-
-  if (n_build)
-    hipLaunchKernelGGL(join_insert_count_kernel, dim3(grid_for(n_build, dev, 8)), dim3(kJoinThreads), 0,
-                       s, build_keys, n_build, keys, cnt, mask, hdr);
-  const size_t tiles = L.cap / kScanTileElems;
-  const size_t cap_grid =
-      static_cast<size_t>(dev.cus) * resident_blocks_per_cu(join_scan_kernel, kJoinThreads, 0, 4);
-  hipLaunchKernelGGL(join_scan_kernel, dim3(static_cast<unsigned>(tiles < cap_grid ? tiles : cap_grid)),
-                     dim3(kJoinThreads), 0, s, cnt, pos, L.cap, hdr, gran, tiles);
-  if (n_build)
-    hipLaunchKernelGGL(join_fill_ids_kernel, dim3(grid_for(n_build, dev, 8)), dim3(kJoinThreads), 0, s,
-                       build_keys, n_build, row_ids, keys, pos, mask, ids);
-  return launch_status();
+  return join_lds_build(build_keys, row_ids, n_build, ids, workspace, as_stream(stream), dev);
 }
 }  // namespace
 
@@ -309,25 +136,15 @@ extern "C" int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, 
                                     size_t n_build, uint32_t *out_pos, uint32_t *out_count,
                                     dbhip_stream_t stream) {
   if (n_probe == 0) return DBHIP_OK;
-  if (!probe_keys || !workspace || !out_pos || !out_count) return DBHIP_EINVAL;
+  if (!probe_keys || !workspace || !out_pos || !out_count || n_build > kJlMaxRows) return DBHIP_EINVAL;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   // the table geometry is a pure function of the build size: no read-back, no synchronisation
-  if (jl_use(n_build))
-    return join_lds_probe(probe_keys, n_probe, workspace, n_build, out_pos, out_count, as_stream(stream), dev);
-  const JoinLayout L = join_layout(n_build);
-  const char *base = static_cast<const char *>(workspace);
-  const unsigned *keys = reinterpret_cast<const unsigned *>(base + L.keys_off);
-  const unsigned *cnt = reinterpret_cast<const unsigned *>(base + L.cnt_off);
-  const unsigned *pos = reinterpret_cast<const unsigned *>(base + L.pos_off);
-  hipLaunchKernelGGL(join_probe_kernel, dim3(grid_for(n_probe, dev, 8)), dim3(kJoinThreads), 0,
-                     as_stream(stream), probe_keys, n_probe, keys, cnt, pos,
-                     static_cast<unsigned>(L.cap - 1), out_pos, out_count);
-  return launch_status();
+  return join_lds_probe(probe_keys, n_probe, workspace, n_build, out_pos, out_count, as_stream(stream), dev);
 }
 
 extern "C" size_t dbhip_ujoin_workspace_bytes(size_t n_build) {
-  if (jl_use(n_build)) return jl_layout(n_build).total;  // radix-partitioned build, LDS sub-tables (join_lds.hip)
+  if (jl_use_ujoin(n_build)) return jl_layout(n_build).total;  // radix-partitioned build, LDS sub-tables (join_lds.hip)
   return align_up(kWsHeader + 2 * join_capacity(n_build) * sizeof(unsigned), kWsAlign);
 }
 
@@ -339,7 +156,7 @@ extern "C" int dbhip_ujoin_build_u32(const uint32_t *build_keys, const uint32_t 
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
-  if (jl_use(n_build)) return ujoin_lds_build(build_keys, build_vals, n_build, workspace, s, dev);
+  if (jl_use_ujoin(n_build)) return ujoin_lds_build(build_keys, build_vals, n_build, workspace, s, dev);
   const size_t cap = join_capacity(n_build);
   char *base = static_cast<char *>(workspace);
   UjoinHeader *hdr = reinterpret_cast<UjoinHeader *>(base);
@@ -363,7 +180,7 @@ extern "C" int dbhip_ujoin_probe_u32(const uint32_t *probe_keys, const uint32_t 
     return DBHIP_EINVAL;
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
-  if (jl_use(n_build))
+  if (jl_use_ujoin(n_build))
     return ujoin_lds_probe(probe_keys, probe_vals, n_probe, workspace, n_build, out_key, out_build_val, out_probe_val,
                            as_stream(stream), dev);
   const size_t cap = join_capacity(n_build);

@@ -9,12 +9,14 @@ namespace dbhip {
 constexpr unsigned kJlSubSlots = 4096;  // slots of one LDS sub-table (48 KiB of LDS with counts/positions)
 constexpr unsigned kJlSubMask = kJlSubSlots - 1;
 constexpr unsigned kJlRowsPerPart = 2048;           // expected rows per partition (load factor <= 0.5)
-constexpr size_t kJlMinRows = static_cast<size_t>(1) << 16;  // below: the HBM-table path of join.hip
+constexpr size_t kJlMinRows = static_cast<size_t>(1) << 16;  // unique-key join only: below, the CAS table of join.hip
 constexpr size_t kJlMaxRows = static_cast<size_t>(1) << 31;  // above: 2^20 partitions would overfill
 
-inline bool jl_use(size_t n_build) {
+// The unique-key payload join keeps a plain CAS table in HBM below kJlMinRows build rows (fewer launches); the
+// one-to-many join takes the partitioned path at every size.  DBHIP_JOIN_PATH=lds|hbm overrides for experiments.
+inline bool jl_use_ujoin(size_t n_build) {
   static const int force = [] {
-    const char *e = getenv("DBHIP_JOIN_PATH");  // "lds" / "hbm" for experiments; default by size
+    const char *e = getenv("DBHIP_JOIN_PATH");
     return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'h' ? 2 : 0));
   }();
   if (force == 2) return false;

@@ -11,8 +11,8 @@
  * call sequence can be captured into a hipGraph.
  *
  * Return value: 0 on success, a negative DBHIP_E* code for argument errors detected on the host,
- * or a positive hipError_t if a launch failed.  Device-side failures (a bounded spin that timed
- * out, an out-of-range group key, a full hash table) are reported through the status word that
+ * or a positive hipError_t if a launch failed.  Device-side failures (an out-of-range group key,
+ * a full hash table) are reported through the status word that
  * lives at the start of the workspace: read it back with dbhip_workspace_status() after the
  * stream has been synchronised.
  *
@@ -53,7 +53,7 @@ extern "C" {
 
 /* device-side status word values (dbhip_workspace_status) */
 #define DBHIP_DEV_OK 0u
-#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* a look-back wait gave up: result is invalid (small-input join only) */
+#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* reserved: no kernel of this library waits on another workgroup any more */
 #define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count */
 #define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
 
