@@ -401,34 +401,77 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
   // (two 16 KiB arrays instead of three: 4 workgroups per CU instead of 3)
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const size_t part = blockIdx.x;
-  const size_t lo = starts[part], hi = starts[part + 1];
+  constexpr int kJlCached = 8;  // rows per thread whose slot and row id stay in registers between steps 1 and 3
+  constexpr int kJlPre = 4;     // rows per thread loaded one partition ahead (a partition holds ~2048 rows = 4 per thread)
 
-  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
-    lk[i] = kEmptyKey;
-    lc[i] = 0;
-  }
-  __syncthreads();
-  // 1. claim the key's slot (ds_cmpst) and count the row (ds_add).  The slot and row id of a thread's first
-  //    kJlCached rows stay in registers for step 3 (a partition holds ~2048 rows = 4 per thread).
-  constexpr int kJlCached = 8;
-  unsigned c_slot[kJlCached], c_rid[kJlCached];
+  // Persistent workgroups walk the partitions with a stride of the grid; a workgroup is a chain of dependent
+  // phases (load, claim, scan, fill, publish), so the NEXT partition's rows are requested before the current
+  // partition's LDS work starts and arrive while it runs.
+  size_t part = blockIdx.x;
+  if (part >= parts) return;
+  size_t lo = starts[part], hi = starts[part + 1];
+  u32x2 pre[kJlPre];
 #pragma unroll
-  for (int r = 0; r < kJlCached; ++r) {
+  for (int r = 0; r < kJlPre; ++r) {
     const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
-    c_slot[r] = kJlSubSlots;  // "no row"
-    c_rid[r] = 0;
-    if (i < hi) {
-      const u32x2 row = jl_row(pkeys, prids, i);
-      const unsigned key = row.x;
-      c_rid[r] = row.y;
+    pre[r] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+  }
+  while (true) {
+    for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
+      lk[i] = kEmptyKey;
+      lc[i] = 0;
+    }
+    u32x2 cur[kJlPre];
+#pragma unroll
+    for (int r = 0; r < kJlPre; ++r) cur[r] = pre[r];
+    const size_t npart = part + gridDim.x;
+    size_t nlo = 0, nhi = 0;
+    if (npart < parts) {
+      nlo = starts[npart];
+      nhi = starts[npart + 1];
+#pragma unroll
+      for (int r = 0; r < kJlPre; ++r) {
+        const size_t i = nlo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+        pre[r] = i < nhi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+      }
+    }
+    __syncthreads();
+    // 1. claim the key's slot (ds_cmpst) and count the row (ds_add)
+    unsigned c_slot[kJlCached], c_rid[kJlCached];
+#pragma unroll
+    for (int r = 0; r < kJlCached; ++r) {
+      const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+      c_slot[r] = kJlSubSlots;  // "no row"
+      c_rid[r] = 0;
+      if (i < hi) {
+        const u32x2 row = r < kJlPre ? cur[r < kJlPre ? r : 0] : jl_row(pkeys, prids, i);
+        const unsigned key = row.x;
+        c_rid[r] = row.y;
+        unsigned s = fmix32(key) & kJlSubMask;
+        unsigned tries = 0;
+        while (true) {
+          const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
+          if (old == kEmptyKey || old == key) {
+            atomicAdd(&lc[s], 1u);
+            c_slot[r] = s;
+            break;
+          }
+          s = (s + 1) & kJlSubMask;
+          if (++tries > kJlSubMask) {
+            atomicOr(status, DBHIP_DEV_TABLE_FULL);
+            break;
+          }
+        }
+      }
+    }
+    for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
+      const unsigned key = jl_row(pkeys, prids, i).x;
       unsigned s = fmix32(key) & kJlSubMask;
       unsigned tries = 0;
       while (true) {
         const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
         if (old == kEmptyKey || old == key) {
           atomicAdd(&lc[s], 1u);
-          c_slot[r] = s;
           break;
         }
         s = (s + 1) & kJlSubMask;
@@ -438,63 +481,51 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
         }
       }
     }
-  }
-  for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-    const unsigned key = jl_row(pkeys, prids, i).x;
-    unsigned s = fmix32(key) & kJlSubMask;
-    unsigned tries = 0;
-    while (true) {
-      const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
-      if (old == kEmptyKey || old == key) {
-        atomicAdd(&lc[s], 1u);
-        break;
-      }
-      s = (s + 1) & kJlSubMask;
-      if (++tries > kJlSubMask) {
-        atomicOr(status, DBHIP_DEV_TABLE_FULL);
-        break;
-      }
+    __syncthreads();
+    // 2. exclusive scan of the 4096 counts -> first id position of every slot (8 slots per thread)
+    constexpr unsigned kPer = kJlSubSlots / kJlBuildThreads;
+    unsigned c[kPer], mine = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kPer; ++j) {
+      c[j] = lc[tid * kPer + j];
+      mine += c[j];
     }
-  }
-  __syncthreads();
-  // 2. exclusive scan of the 8192 counts -> first id position of every slot (8 slots per thread)
-  constexpr unsigned kPer = kJlSubSlots / kJlBuildThreads;
-  unsigned c[kPer], mine = 0;
+    const unsigned incl = wave_inclusive_scan(mine);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned run = static_cast<unsigned>(lo) + incl - mine;
+    for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+    // every thread has its 8 counts in registers (the barrier above): overwrite them with the positions
 #pragma unroll
-  for (unsigned j = 0; j < kPer; ++j) {
-    c[j] = lc[tid * kPer + j];
-    mine += c[j];
-  }
-  const unsigned incl = wave_inclusive_scan(mine);
-  if (lane == kWave - 1) s_wsum[wave] = incl;
-  __syncthreads();
-  unsigned run = static_cast<unsigned>(lo) + incl - mine;
-  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
-  // every thread has its 8 counts in registers (the barrier above): overwrite them with the positions
+    for (unsigned j = 0; j < kPer; ++j) {
+      lp[tid * kPer + j] = run;
+      run += c[j];
+    }
+    __syncthreads();
+    // 3. fill: ids[pos[slot]++] = row id — from the registers of step 1, the overflow rows are read again
 #pragma unroll
-  for (unsigned j = 0; j < kPer; ++j) {
-    lp[tid * kPer + j] = run;
-    run += c[j];
+    for (int r = 0; r < kJlCached; ++r)
+      if (c_slot[r] < kJlSubSlots) ids[atomicAdd(&lp[c_slot[r]], 1u)] = c_rid[r];
+    for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
+      const u32x2 row = jl_row(pkeys, prids, i);
+      const unsigned key = row.x;
+      unsigned s = fmix32(key) & kJlSubMask;
+      for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
+      if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
+    }
+    __syncthreads();
+    // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot
+    //    i's ids, and positions are an exclusive scan in slot order, so slot i starts where slot i-1 ends.
+    u32x2 *dst = table + part * kJlSubSlots;
+    for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads)
+      dst[i] = u32x2{lk[i], i ? lp[i - 1] : static_cast<unsigned>(lo)};
+    if (part + 1 == parts && tid == 0) dst[kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // right neighbour of the last slot
+    if (npart >= parts) break;
+    __syncthreads();  // the LDS arrays and s_wsum are reused by the next partition
+    part = npart;
+    lo = nlo;
+    hi = nhi;
   }
-  __syncthreads();
-  // 3. fill: ids[pos[slot]++] = row id — from the registers of step 1, the overflow rows are read again
-#pragma unroll
-  for (int r = 0; r < kJlCached; ++r)
-    if (c_slot[r] < kJlSubSlots) ids[atomicAdd(&lp[c_slot[r]], 1u)] = c_rid[r];
-  for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-    const u32x2 row = jl_row(pkeys, prids, i);
-    const unsigned key = row.x;
-    unsigned s = fmix32(key) & kJlSubMask;
-    for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
-    if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
-  }
-  __syncthreads();
-  // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot i's
-  //    ids, and positions are an exclusive scan in slot order, so slot i starts where slot i-1 ends.
-  u32x2 *dst = table + part * kJlSubSlots;
-  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads)
-    dst[i] = u32x2{lk[i], i ? lp[i - 1] : static_cast<unsigned>(lo)};
-  if (part + 1 == parts && tid == 0) dst[kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // right neighbour of the last slot
 }
 
 __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
@@ -687,7 +718,9 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(jl_build_kernel, dim3(L.parts), dim3(kJlBuildThreads), build_lds, s, p.keys, p.rids, p.starts,
+  const size_t build_cap = static_cast<size_t>(dev.cus) * 4;  // four 512-thread workgroups per CU (32 KiB of LDS each)
+  hipLaunchKernelGGL(jl_build_kernel, dim3(static_cast<unsigned>(L.parts < build_cap ? L.parts : build_cap)),
+                     dim3(kJlBuildThreads), build_lds, s, p.keys, p.rids, p.starts,
                      p.table, L.parts, static_cast<unsigned>(n), ids, p.status);
   return launch_status();
 }
