@@ -34,6 +34,7 @@ SIGNATURES = {
     "dbhip_join_build_u32": (_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_build_pairs_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_probe_u32": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dbhip_join_answers_u32": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "dbhip_ujoin_workspace_bytes": (_sz, [_sz]),
     "dbhip_ujoin_build_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "dbhip_ujoin_probe_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
@@ -46,6 +47,17 @@ SIGNATURES = {
     "dbhip_gather_u32": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "dbhip_reduce_sum_i32": (_int, [_vp, _sz, _vp, _vp]),
     "dbhip_nested_join_u32": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "dbhip_exclusive_scan_u32_workspace_bytes": (_sz, [_sz]),
+    "dbhip_exclusive_scan_u32": (_int, [_vp, _sz, _u32, _vp, _vp, _sz, _vp]),
+    "dbhip_check_fingerprint_workspace_bytes": (_sz, [_sz]),
+    "dbhip_check_fingerprint_lt_i32": (_int, [_vp, _sz, _i32, _vp, _vp, _sz, _vp]),
+    "dbhip_check_sorted_u32": (_int, [_vp, _sz, _int, _vp, _vp]),
+    "dbhip_check_weighted_sum_u32": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "dbhip_check_permutation_workspace_bytes": (_sz, [_sz]),
+    "dbhip_check_permutation_u32": (_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "dbhip_check_join_u32": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _u64, _u32, _u32, _vp, _vp]),
+    "dbhip_check_ujoin_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "dbhip_check_gen_uniform_u32": (_int, [_vp, _vp, _sz, _u64, _u64, _u32, _u32, _vp, _vp]),
 }
 
 _lib = None

@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned long long wave_reduce_add_u64(unsigned long 
 }
 
 
-// splitmix64-style counter hash shared with oracle/dbo_gen.c (must stay bit-identical)
+// splitmix64-style counter hash shared with dbo_mix64 in oracle/dbo.c (must stay bit-identical)
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t i) {
   uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
   z ^= z >> 30;

@@ -1,5 +1,5 @@
 // dbhip_util.hip — library/device queries, workspace status read-back and the deterministic
-// counter-based data generators (device twins of oracle/dbo_gen.c).
+// counter-based data generators (device twins of dbo_gen_uniform_u32 / dbo_gen_unique_sorted_u32 in oracle/dbo.c).
 #include <cstring>
 #include <mutex>
 

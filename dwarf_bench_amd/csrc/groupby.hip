@@ -88,7 +88,8 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
     slot = b / geo.ranges;
   }
   const unsigned lo = range * geo.range_groups;
-  const unsigned hi_excl = lo + geo.range_groups < groups ? lo + geo.range_groups : groups;
+  const unsigned long long hi64 = static_cast<unsigned long long>(lo) + geo.range_groups;  // may pass 2^32
+  const unsigned hi_excl = hi64 < groups ? static_cast<unsigned>(hi64) : groups;
   const unsigned span = hi_excl > lo ? hi_excl - lo : 0;
   const unsigned rep_off = (tid % geo.replicas) * geo.rep_stride;
 
@@ -191,9 +192,14 @@ GbGeometry gb_launch_geometry(uint32_t groups, uint32_t max_tables, int cus) {
 
 int gb_partial(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups, uint32_t max_tables,
                void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
-  if (groups == 0) return n == 0 ? DBHIP_OK : DBHIP_EINVAL;
+  if (groups == 0) {
+    if (n) return DBHIP_EINVAL;
+    if (workspace && ws_ok(workspace, workspace_bytes, kWsHeader))  // a clean status word even when nothing runs
+      return static_cast<int>(fill_async(workspace, 0, kWsHeader, as_stream(stream)));
+    return DBHIP_OK;
+  }
   if (n && (!keys || !vals)) return DBHIP_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(vals)) & 15u) return DBHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(vals)) & 15u) return DBHIP_EINVAL;  // dbhip.h: 16-byte aligned
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   const GbGeometry geo = gb_launch_geometry(groups, max_tables, dev.cus);

@@ -37,7 +37,7 @@ inline unsigned grid_for(size_t n, const DeviceInfo &dev, int per_cu) {
 __device__ __forceinline__ unsigned find_slot(const unsigned *__restrict__ keys, unsigned key,
                                               unsigned mask, bool *found) {
   unsigned s = fmix32(key) & mask;
-  for (unsigned tries = 0; tries <= mask; ++tries) {
+  for (unsigned tries = 0; tries <= mask && key != kEmpty; ++tries) {
     const unsigned k = keys[s];
     if (k == key) {
       *found = true;
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(kJoinThreads) void ujoin_build_kernel(const unsigne
     const unsigned key = bkeys[i];
     unsigned s = fmix32(key) & mask;
     unsigned tries = 0;
+    if (key == kEmpty) {  // the sentinel is not a key: flag it, drop the row
+      atomicOr(&hdr->status, DBHIP_DEV_KEY_RANGE);
+      continue;
+    }
     while (true) {
       const unsigned old = atomicCAS(&keys[s], kEmpty, key);
       if (old == kEmpty) {  // claimed: the payload store is read only by the next launch

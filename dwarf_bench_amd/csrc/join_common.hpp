@@ -1,5 +1,5 @@
-// join_common.hpp — geometry shared by join.hip (entry points, HBM-table path) and join_lds.hip
-// (radix-partitioned build with LDS sub-tables).  Everything is a pure function of n_build, so build
+// join_common.hpp — geometry shared by join.hip (the C entry points, the small-input unique-key table, the
+// bitmask-claimed table) and join_lds.hip (radix-partitioned build with LDS sub-tables, every size).  Everything is a pure function of n_build, so build
 // and probe agree without reading anything back from the device.
 #pragma once
 #include "dbhip_common.hpp"

@@ -1,6 +1,5 @@
-// join_lds.hip — dwarf 4a for large build sides: radix-partitioned build with LDS-resident sub-tables,
-// single-gather probe.  Same OmniSci semantics and outputs as join.hip (which stays the path for small
-// inputs): distinct-key table, per-key count, exclusive scan -> position, ids grouped by key, probe ->
+// join_lds.hip — dwarf 4a at every size (and dwarf 4b from 2^16 build rows): radix-partitioned build with
+// LDS-resident sub-tables, single-gather probe.  OmniSci semantics: distinct-key table, per-key count, exclusive scan -> position, ids grouped by key, probe ->
 // {offset, count} (common/dpcpp/omnisci_hashtable.hpp:58-261).
 //
 // Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
@@ -450,6 +449,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
         c_rid[r] = row.y;
         unsigned s = fmix32(key) & kJlSubMask;
         unsigned tries = 0;
+        if (key == kEmptyKey) {  // the sentinel is not a key (join/join_omnisci.cpp:52): flag it, drop the row
+          atomicOr(status, DBHIP_DEV_KEY_RANGE);
+          continue;
+        }
         while (true) {
           const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
           if (old == kEmptyKey || old == key) {
@@ -469,6 +472,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       const unsigned key = jl_row(pkeys, prids, i).x;
       unsigned s = fmix32(key) & kJlSubMask;
       unsigned tries = 0;
+      if (key == kEmptyKey) {
+        atomicOr(status, DBHIP_DEV_KEY_RANGE);
+        continue;
+      }
       while (true) {
         const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
         if (old == kEmptyKey || old == key) {
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       const unsigned key = row.x;
       unsigned s = fmix32(key) & kJlSubMask;
       for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
-      if (lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
+      if (key != kEmptyKey && lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
     }
     __syncthreads();
     // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__
     const unsigned h = fmix32(key);
     const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
     unsigned s = h & kJlSubMask, pos = 0, cnt = 0;
-    for (unsigned tries = 0; tries <= kJlSubMask; ++tries) {
+    for (unsigned tries = 0; tries <= kJlSubMask && key != kEmptyKey; ++tries) {  // the sentinel never matches
       const u32x4 e = *reinterpret_cast<const u32x4_a8 *>(sub + s);  // {key, first, next slot's key, next slot's first}
       if (e.x == key) {
         pos = e.y;
@@ -579,6 +586,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
     const u32x2 row = jl_row(pkeys, prids, i);
     const unsigned key = row.x;
     unsigned s = fmix32(key) & kJlSubMask;
+    if (key == kEmptyKey) {  // the sentinel is not a key: flag it, drop the row
+      atomicOr(status, DBHIP_DEV_KEY_RANGE);
+      continue;
+    }
     for (unsigned tries = 0;; ++tries) {
       const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
       if (old == kEmptyKey) {
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
     const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
     unsigned s = h & kJlSubMask, bval = kEmptyKey;
     bool found = false;
-    for (unsigned tries = 0; tries <= kJlSubMask; ++tries) {
+    for (unsigned tries = 0; tries <= kJlSubMask && key != kEmptyKey; ++tries) {
       const u32x2 e = sub[s];
       if (e.x == key) {
         found = true;

@@ -31,10 +31,33 @@ __global__ __launch_bounds__(kPjThreads) void gather_u32_kernel(const unsigned *
     out[i] = table[idx[i]];
 }
 
+// (position, count) columns -> the reference's JoinOneToMany records {pointer into ids, size}
+__global__ __launch_bounds__(kPjThreads) void join_answers_kernel(const unsigned *__restrict__ ids,
+                                                                  const unsigned *__restrict__ pos,
+                                                                  const unsigned *__restrict__ cnt, size_t n,
+                                                                  dbhip_join_one_to_many *__restrict__ answers) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kPjThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kPjThreads + threadIdx.x; i < n; i += stride)
+    answers[i] = dbhip_join_one_to_many{ids + pos[i], cnt[i]};
+}
+
 }  // namespace
 }  // namespace dbhip
 
 using namespace dbhip;
+
+extern "C" int dbhip_join_answers_u32(const uint32_t *ids, const uint32_t *out_pos, const uint32_t *out_count,
+                                      size_t n_probe, dbhip_join_one_to_many *answers, dbhip_stream_t stream) {
+  if (n_probe == 0) return DBHIP_OK;
+  if (!out_pos || !out_count || !answers) return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  const size_t want = (n_probe + kPjThreads - 1) / kPjThreads;
+  const size_t cap = static_cast<size_t>(dev.cus) * 8;
+  hipLaunchKernelGGL(join_answers_kernel, dim3(static_cast<unsigned>(want < cap ? want : cap)), dim3(kPjThreads), 0,
+                     as_stream(stream), ids, out_pos, out_count, n_probe, answers);
+  return launch_status();
+}
 
 extern "C" size_t dbhip_pjoin_partition_workspace_bytes(size_t n, uint32_t parts) {
   (void)n;

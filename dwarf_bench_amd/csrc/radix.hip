@@ -578,9 +578,13 @@ int radix_sort_entry(unsigned *keys, unsigned *tmp, size_t n, int radix_bits, un
                      void *workspace, size_t workspace_bytes, dbhip_stream_t stream) {
   if (radix_bits != 4 && radix_bits != 8) return DBHIP_EINVAL;
   if (n >= (1ull << 32)) return DBHIP_EINVAL;  // 32-bit offsets
-  if (n == 0) return DBHIP_OK;
+  if (n == 0) {  // nothing to sort; a workspace that was passed still gets a clean status word
+    if (workspace && ws_ok(workspace, workspace_bytes, kWsHeader))
+      return static_cast<int>(fill_async(workspace, 0, kWsHeader, as_stream(stream)));
+    return DBHIP_OK;
+  }
   if (!keys || !tmp) return DBHIP_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) return DBHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(tmp)) & 15u) return DBHIP_EINVAL;  // dbhip.h: 16-byte aligned
   if (!ws_ok(workspace, workspace_bytes, dbhip_radix_sort_workspace_bytes(n, radix_bits)))
     return DBHIP_EWORKSPACE;
   const DeviceInfo &dev = current_device_info();

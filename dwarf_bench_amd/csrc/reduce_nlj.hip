@@ -19,10 +19,15 @@ constexpr int kRedThreads = 512;
 constexpr int kRedVecsPerLane = 8;  // 8 x 16 B in flight per lane
 constexpr size_t kRedTileInts = static_cast<size_t>(kRedThreads) * kRedVecsPerLane * 4;  // 64 KiB tiles
 
-__global__ __launch_bounds__(kRedThreads) void reduce_sum_kernel(const int *__restrict__ src, size_t n,
+__global__ __launch_bounds__(kRedThreads) void reduce_sum_kernel(const int *__restrict__ src, size_t n, unsigned head,
                                                                  unsigned *__restrict__ out) {
+  // `head` (0..3) elements in front of the first 16-byte boundary are added one by one by the first workgroup;
+  // the vector loads start behind them
   __shared__ unsigned wave_sums[kRedThreads / kWave];
   unsigned acc = 0;
+  if (blockIdx.x == 0 && threadIdx.x < head) acc += static_cast<unsigned>(src[threadIdx.x]);
+  src += head;
+  n -= head;
   const size_t full_tiles = n / kRedTileInts;
   const i32x4 *vsrc = reinterpret_cast<const i32x4 *>(src);
   for (size_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
@@ -93,7 +98,9 @@ extern "C" int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, 
   const size_t tiles = (n + kRedTileInts - 1) / kRedTileInts;
   const size_t cap = static_cast<size_t>(dev.cus) * 4;  // 4 x 512 threads per CU: full occupancy
   const unsigned grid = static_cast<unsigned>(tiles < cap ? tiles : cap);
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid), dim3(kRedThreads), 0, s, src, n,
+  size_t head = ((16 - (reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / 4;  // src is 4-byte aligned (int32)
+  if (head > n) head = n;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid), dim3(kRedThreads), 0, s, src, n, static_cast<unsigned>(head),
                      reinterpret_cast<unsigned *>(out));
   return launch_status();
 }

@@ -86,28 +86,18 @@ __device__ __forceinline__ void emit_wave_matches(const i32x4 (&v)[kScanVpt], in
 }
 
 // =================================================================================================
-// Small inputs: one tile at a time per workgroup, immediate look-back, direct writes.
-// =================================================================================================
-// =================================================================================================
 // Chunked path, two kernels, NO communication between workgroups while streaming.
 //
-// History: the first version was a single-pass kernel with decoupled look-back (tickets, 8-byte {state, value}
-// granules, bounded spins).  It survives in join.hip's slot scan; here it lost at every size:
-// Measured on MI355X (profiles/): with all 256 CUs streaming, ~30 MiB of loads are in flight and any
-// read that must come from memory — a look-back poll included — takes 3.5-4.5 us, as long as a CU
-// needs for a whole 128 KiB tile, and 256 CUs polling the same few KiB of granules overload the
-// HBM channels that hold them.  A single-pass look-back therefore tops out near 50 % of the
-// streaming rate however it is pipelined (immediate, deferred by one or two tiles through an LDS
-// ring, replicated granules: all between 255 and 340 us at 2^28 against 160 us for the bare stream).
-// and at small sizes the two launches below are level with its fill + kernel (2^10..2^18 elements: 12.9-14.2 us
-// against 14.3-16.1 us).  So the dependency is removed instead of hidden:
+// Why not a single-pass decoupled look-back (measured history in DESIGN.md 4.1): with all 256 CUs streaming,
+// ~30 MiB of loads are in flight and any read that must come from memory — a look-back poll included — takes
+// 3.5-4.5 us, as long as a CU needs for a whole 128 KiB tile; every variant built landed between 255 and 340 us
+// at 2^28 against 160 us for the bare stream.  So the dependency is removed instead of hidden:
 //   scan_chunk_kernel  chunks (1 MiB for large inputs) are dealt by blockIdx — nothing here waits on another
 //                      workgroup, so no ticket and no zeroed header are needed: the call is two launches.
-//                      A 16-wave workgroup streams its chunk
-//                      tile by tile (128 KiB, double-buffered registers, next tile's loads issued
-//                      right after the count, a barrier that does not drain vmcnt), ranks matches
-//                      with ballots/mbcnt and writes them to the chunk's own slot of a staging buffer at
-//                      chunk-local offsets; one count per chunk.
+//                      A 16-wave workgroup streams its chunk tile by tile (128 KiB, double-buffered registers,
+//                      next tile's loads issued right after the count, a barrier that does not drain vmcnt),
+//                      ranks matches with ballots/mbcnt and writes them to the chunk's own slot of a staging
+//                      buffer at chunk-local offsets; one count per chunk.
 //   scan_move_kernel   one workgroup per chunk: prefix of the chunk counts (<= 4 KiB, read from L2),
 //                      then a coalesced copy staging -> out at the global offset; writes out_size and the
 //                      (always clean) status word.

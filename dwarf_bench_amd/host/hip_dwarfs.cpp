@@ -7,10 +7,18 @@
 //   * inputs are generated ON the device by the counter-based generators of libdbhip (deterministic
 //     seeds instead of std::random_device, common/common.hpp:34-35) and stay resident: host_time does
 //     not contain the reference's H2D/D2H of whole columns (scan/scan.cpp:108-120);
-//   * validation uses the same host algorithms the reference dwarfs use (std::copy_if, std::sort, the
-//     expected_GroupBy loop, per-key match counts) and is ALWAYS on — the reference only validates
-//     DPLScan/Radix/GroupBy/JoinOmnisci in Debug builds — but is skipped above
-//     DWARF_BENCH_VALIDATE_MAX elements (default 2^24) where a host check would dominate the run;
+//   * validation is ALWAYS on and covers every size (the reference validates every iteration at every size,
+//     scan/scan.cpp:157-164, but DPLScan/Radix/GroupBy/JoinOmnisci only in Debug builds): up to
+//     DWARF_BENCH_VALIDATE_MAX elements (default 2^24) with the same host algorithms the reference dwarfs use
+//     (std::copy_if, std::sort, the expected_GroupBy loop, per-key match counts); above it, where a host check
+//     would dominate the run or not fit, with the device-side validators of libdbhip (dbhip_check_*: ordered
+//     fingerprint of the compaction, sortedness + multiset fingerprint, weighted group sums, per-row match
+//     counts against the sorted build column + id permutation).  DWARF_BENCH_INJECT_FAULT=1 corrupts one word
+//     of every result before it is checked: every Result must then come out valid = false (tests use it to
+//     show that the checks can fail);
+//   * DWARF_BENCH_TIME_TRANSFERS=1 (scan dwarfs): host_time then contains the blocking H2D of src and the D2H
+//     of all n output ints, exactly the reference's timed region (scan/scan.cpp:107-128), so the figure is
+//     comparable with existing dwarf_bench CSVs;
 //   * HIP failures throw DwarfBenchException (setup errors are exceptions in the reference too).
 #include "hip_dwarfs.hpp"
 
@@ -109,6 +117,41 @@ size_t validate_limit() {
   return v;
 }
 
+bool env_flag(const char *name) {
+  const char *e = std::getenv(name);
+  return e && std::atoi(e) != 0;
+}
+bool inject_fault() {
+  static const bool v = env_flag("DWARF_BENCH_INJECT_FAULT");
+  return v;
+}
+bool time_transfers() {
+  static const bool v = env_flag("DWARF_BENCH_TIME_TRANSFERS");
+  return v;
+}
+// fault injection: flip bits of one device word (after the timed region, before the check)
+void poke_xor(void *dev_word, uint32_t mask) {
+  uint32_t h = 0;
+  hip_ok(hipMemcpy(&h, dev_word, sizeof(h), hipMemcpyDeviceToHost), "poke D2H");
+  h ^= mask;
+  hip_ok(hipMemcpy(dev_word, &h, sizeof(h), hipMemcpyHostToDevice), "poke H2D");
+}
+
+// result words of a dbhip_check_* call
+class CheckWords {
+ public:
+  CheckWords() : dev_(4) {}
+  uint64_t *dev() const { return dev_.get(); }
+  std::array<uint64_t, 4> get() const {
+    std::array<uint64_t, 4> h{};
+    hip_ok(hipMemcpy(h.data(), dev_.get(), sizeof(h), hipMemcpyDeviceToHost), "check D2H");  // syncs the null stream
+    return h;
+  }
+
+ private:
+  DevBuf<uint64_t> dev_;
+};
+
 void check_status(const void *ws, const char *what) {
   uint32_t st = 0xFFFFFFFFu;
   db_ok(dbhip_workspace_status(ws, &st, nullptr), "dbhip_workspace_status");
@@ -144,20 +187,39 @@ void run_scan(const char *who, size_t n, Meter &meter) {
   hip_ok(hipDeviceSynchronize(), "sync");
 
   std::vector<int32_t> expected;
-  const bool validate = n <= validate_limit();
-  if (validate) {  // scan/scan.cpp:12-17 expected_out_lt
+  const bool host_check = n <= validate_limit();
+  CheckWords want, got;
+  const size_t fp_bytes = dbhip_check_fingerprint_workspace_bytes(n);
+  DevBuf<unsigned char> fp_ws(fp_bytes);
+  std::array<uint64_t, 4> want_fp{};
+  if (host_check) {  // scan/scan.cpp:12-17 expected_out_lt
     const std::vector<int32_t> host = src.to_host(n);
     std::copy_if(host.begin(), host.end(), std::back_inserter(expected),
                  [](int v) { return v < filter_value; });
+  } else {  // order-sensitive fingerprint + length of the matching subsequence, straight from src
+    db_ok(dbhip_check_fingerprint_lt_i32(src.get(), n, filter_value, want.dev(), fp_ws.get(), fp_bytes, nullptr),
+          "dbhip_check_fingerprint_lt_i32");
+    want_fp = want.get();
+  }
+  // DWARF_BENCH_TIME_TRANSFERS=1: the reference's timed region (scan/scan.cpp:107-128) — blocking write of src,
+  // kernel, blocking read of all n output ints and of out_size — from/to pageable host vectors like the reference's
+  std::vector<int32_t> host_src, host_out;
+  if (time_transfers()) {
+    host_src = src.to_host(n);
+    host_out.resize(n);
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
     auto result = std::make_unique<Result>();
     const auto host_start = clk::now();
+    if (time_transfers() && n)
+      hip_ok(hipMemcpy(src.get(), host_src.data(), n * sizeof(int32_t), hipMemcpyHostToDevice), "src H2D");
     hip_ok(hipEventRecord(ev.a, nullptr), "event");
     db_ok(dbhip_copy_if_lt_i32(src.get(), n, filter_value, out.get(), out_size.get(), ws.get(), ws_bytes, nullptr),
           "dbhip_copy_if_lt_i32");
     hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    if (time_transfers() && n)
+      hip_ok(hipMemcpy(host_out.data(), out.get(), n * sizeof(int32_t), hipMemcpyDeviceToHost), "out D2H");
     uint64_t count = 0;
     hip_ok(hipMemcpy(&count, out_size.get(), sizeof(count), hipMemcpyDeviceToHost), "out_size D2H");  // syncs
     const auto host_end = clk::now();
@@ -165,11 +227,20 @@ void run_scan(const char *who, size_t n, Meter &meter) {
     result->kernel_time = ev.elapsed();
     result->bytes = n * sizeof(int32_t) + count * sizeof(int32_t);
     check_status(ws.get(), who);
-    if (validate) {
-      if (count != expected.size() || out.to_host(count) != expected) {
-        std::cerr << "incorrect results" << std::endl;
-        result->valid = false;
-      }
+    if (inject_fault() && count) poke_xor(out.get() + count / 2, 1u);
+    bool ok;
+    if (host_check) {
+      ok = count == expected.size() && out.to_host(count) == expected;
+    } else {  // every element of out passes the filter iff the lengths agree; order and values: the fingerprint
+      db_ok(dbhip_check_fingerprint_lt_i32(out.get(), count <= n ? count : n, filter_value, got.dev(), fp_ws.get(),
+                                           fp_bytes, nullptr),
+            "dbhip_check_fingerprint_lt_i32");
+      const auto g = got.get();
+      ok = count == want_fp[1] && g[1] == want_fp[1] && g[0] == want_fp[0];
+    }
+    if (!ok) {
+      std::cerr << "incorrect results" << std::endl;
+      result->valid = false;
     }
     meter.add_result(size_param(n), std::move(result));
   }
@@ -206,11 +277,16 @@ void RadixHip::_run(const size_t n, Meter &meter) {
   DevBuf<unsigned char> ws(ws_bytes);
   db_ok(dbhip_gen_uniform_u32(reinterpret_cast<uint32_t *>(src.get()), n, 42, 0, 1, 10000, nullptr), "gen");
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   std::vector<int32_t> expected;
-  if (validate) {  // sort/radix.cpp:8-12
+  CheckWords chk;
+  std::array<uint64_t, 4> want{};
+  if (host_check) {  // sort/radix.cpp:8-12
     expected = src.to_host(n);
     std::sort(expected.begin(), expected.end());
+  } else {  // multiset fingerprint of the unsorted column
+    db_ok(dbhip_check_sorted_u32(reinterpret_cast<uint32_t *>(src.get()), n, 1, chk.dev(), nullptr), "dbhip_check_sorted_u32");
+    want = chk.get();
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -227,7 +303,16 @@ void RadixHip::_run(const size_t n, Meter &meter) {
     result->host_time = host_end - host_start;
     result->kernel_time = ev.elapsed();
     if (n) check_status(ws.get(), "RadixHip");
-    if (validate && keys.to_host(n) != expected) {
+    if (inject_fault() && n) poke_xor(keys.get() + n / 2, 0x100u);
+    bool ok;
+    if (host_check) {
+      ok = keys.to_host(n) == expected;
+    } else {  // ascending as int32 and the same multiset as the input
+      db_ok(dbhip_check_sorted_u32(reinterpret_cast<uint32_t *>(keys.get()), n, 1, chk.dev(), nullptr), "dbhip_check_sorted_u32");
+      const auto g = chk.get();
+      ok = g[0] == 0 && g[1] == want[1] && g[2] == want[2];
+    }
+    if (!ok) {
       std::cerr << "incorrect results" << std::endl;
       result->valid = false;
     }
@@ -252,12 +337,17 @@ void GroupByHip::_run(const size_t n, Meter &meter) {
   db_ok(dbhip_gen_uniform_u32(vals.get(), n, 43, 0, 1, 10000, nullptr), "gen vals");        // groupby.cpp:29-30
   db_ok(dbhip_gen_uniform_u32(keys.get(), n, 42, 0, 0, groups - 1, nullptr), "gen keys");  // groupby.cpp:31-32
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   std::vector<uint32_t> expected(groups, 0);
-  if (validate) {  // groupby/groupby.cpp:8-19 expected_GroupBy with f = +
+  CheckWords chk;
+  std::array<uint64_t, 4> want{};
+  if (host_check) {  // groupby/groupby.cpp:8-19 expected_GroupBy with f = +
     const auto hk = keys.to_host(n);
     const auto hv = vals.to_host(n);
     for (size_t i = 0; i < n; ++i) expected[hk[i]] = expected[hk[i]] + hv[i];
+  } else {  // sum of val * w(key) mod 2^32 for two weight functions, over the rows
+    db_ok(dbhip_check_weighted_sum_u32(keys.get(), vals.get(), n, chk.dev(), nullptr), "dbhip_check_weighted_sum_u32");
+    want = chk.get();
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -272,7 +362,16 @@ void GroupByHip::_run(const size_t n, Meter &meter) {
     result->host_time = host_end - host_start;
     result->kernel_time = ev.elapsed();
     check_status(ws.get(), "GroupByHip");
-    if (validate && out.to_host(groups) != expected) {
+    if (inject_fault()) poke_xor(out.get() + groups / 2, 1u);
+    bool ok;
+    if (host_check) {
+      ok = out.to_host(groups) == expected;
+    } else {  // ... and over (g, out[g]): equal iff every row's value reached its own group (mod 2^32, as the sums)
+      db_ok(dbhip_check_weighted_sum_u32(nullptr, out.get(), groups, chk.dev(), nullptr), "dbhip_check_weighted_sum_u32");
+      const auto g = chk.get();
+      ok = g[0] == want[0] && g[1] == want[1];
+    }
+    if (!ok) {
       std::cerr << "Incorrect results" << std::endl;
       result->valid = false;
     }
@@ -295,13 +394,25 @@ void JoinOmnisciHip::_run(const size_t n, Meter &meter) {
   db_ok(dbhip_gen_uniform_u32(a.get(), n, 42, 0, 1, 10000, nullptr), "gen a");  // join_omnisci.cpp:53-58
   db_ok(dbhip_gen_uniform_u32(b.get(), n, 43, 0, 1, 10000, nullptr), "gen b");
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   std::vector<uint32_t> ha, hb;
   std::unordered_map<uint32_t, uint32_t> key_count;
-  if (validate) {
+  // device-side check above the host limit: the build column sorted (an algorithm that shares nothing with the
+  // hash join) gives every probe key's exact multiplicity by binary search
+  DevBuf<uint32_t> sorted_a(host_check ? 0 : n), sort_tmp(host_check ? 0 : n);
+  const size_t perm_bytes = dbhip_check_permutation_workspace_bytes(n);
+  DevBuf<unsigned char> perm_ws(host_check ? 0 : perm_bytes);
+  CheckWords chk;
+  if (host_check) {
     ha = a.to_host(n);
     hb = b.to_host(n);
     for (uint32_t k : ha) ++key_count[k];
+  } else {
+    const size_t sort_bytes = dbhip_radix_sort_workspace_bytes(n, 8);
+    DevBuf<unsigned char> sort_ws(sort_bytes);
+    hip_ok(hipMemcpy(sorted_a.get(), a.get(), n * sizeof(uint32_t), hipMemcpyDeviceToDevice), "copy");
+    db_ok(dbhip_radix_sort_u32(sorted_a.get(), sort_tmp.get(), n, 8, sort_ws.get(), sort_bytes, nullptr), "sort build keys");
+    hip_ok(hipDeviceSynchronize(), "sync");
   }
   Events build_ev, probe_ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -322,21 +433,38 @@ void JoinOmnisciHip::_run(const size_t n, Meter &meter) {
     result->probe_time = host_end - build_end;
     result->kernel_time = build_ev.elapsed() + probe_ev.elapsed();
     check_status(ws.get(), "JoinOmnisciHip");
-    if (validate) {
-      // join/join_omnisci.cpp:31-45 are_equal: size per probe row + every returned id really matches
+    if (inject_fault() && n) poke_xor(cnt.get() + n / 2, 1u);
+    bool ok = true;
+    if (host_check) {
+      // join/join_omnisci.cpp:31-45 are_equal: size per probe row + every returned id really matches; on top of
+      // it the id buffer must be a permutation of the build rows (a key's ids are then distinct rows)
       const auto hpos = pos.to_host(n), hcnt = cnt.to_host(n), hids = ids.to_host(n);
-      bool ok = true;
+      std::vector<char> seen(n, 0);
+      for (size_t j = 0; j < n && ok; ++j) {
+        ok = hids[j] < n && !seen[hids[j]];
+        if (ok) seen[hids[j]] = 1;
+      }
       for (size_t i = 0; i < n && ok; ++i) {
         const auto f = key_count.find(hb[i]);
         const uint32_t want = f == key_count.end() ? 0u : f->second;
-        ok = hcnt[i] == want;
-        for (uint32_t j = 0; ok && j < hcnt[i]; j += (hcnt[i] > 64 ? hcnt[i] / 64 : 1))
-          ok = hpos[i] + j < n && hids[hpos[i] + j] < n && ha[hids[hpos[i] + j]] == hb[i];
+        ok = hcnt[i] == want && static_cast<size_t>(hpos[i]) + hcnt[i] <= n;
+        // every id of a short list, a spread of 64 (always with both ends) of a long one
+        const uint32_t step = hcnt[i] > 64 ? hcnt[i] / 64 : 1;
+        for (uint32_t j = 0; ok && j < hcnt[i]; j += step) ok = ha[hids[hpos[i] + j]] == hb[i];
+        if (ok && hcnt[i]) ok = ha[hids[hpos[i] + hcnt[i] - 1]] == hb[i];
       }
-      if (!ok) {
-        std::cerr << "Incorrect results" << std::endl;
-        result->valid = false;
-      }
+    } else {
+      db_ok(dbhip_check_join_u32(sorted_a.get(), n, b.get(), n, pos.get(), cnt.get(), ids.get(), a.get(), 0, 0, 0,
+                                 chk.dev(), nullptr),
+            "dbhip_check_join_u32");
+      const auto g = chk.get();
+      db_ok(dbhip_check_permutation_u32(ids.get(), n, chk.dev(), perm_ws.get(), perm_bytes, nullptr),
+            "dbhip_check_permutation_u32");
+      ok = g[0] == 0 && chk.get()[0] == 0;
+    }
+    if (!ok) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
     }
     meter.add_result(size_param(n), std::move(result));
   }
@@ -361,10 +489,11 @@ void JoinHip::_run(const size_t n, Meter &meter) {
   db_ok(dbhip_gen_unique_sorted_u32(bk.get(), n, 13, 0, nullptr), "gen");
   db_ok(dbhip_gen_unique_sorted_u32(bv.get(), n, 14, 0, nullptr), "gen");
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   std::unordered_map<uint32_t, uint32_t> a_payload;
   std::vector<uint32_t> hbk, hbv;
-  if (validate) {
+  CheckWords chk;
+  if (host_check) {
     const auto hak = ak.to_host(n), hav = av.to_host(n);
     hbk = bk.to_host(n);
     hbv = bv.to_host(n);
@@ -390,10 +519,11 @@ void JoinHip::_run(const size_t n, Meter &meter) {
     result->probe_time = host_end - build_end;
     result->kernel_time = build_ev.elapsed() + probe_ev.elapsed();
     check_status(ws.get(), "JoinHip");
-    if (validate) {
+    if (inject_fault() && n) poke_xor(o1.get() + n / 2, 1u);
+    bool ok = true;
+    if (host_check) {
       // same table as seq_join would produce (join.cpp:27-28, :133): unique keys -> per probe row
       const auto hk = ok_.to_host(n), h1 = o1.to_host(n), h2 = o2.to_host(n);
-      bool ok = true;
       for (size_t i = 0; i < n && ok; ++i) {
         const auto f = a_payload.find(hbk[i]);
         if (f == a_payload.end())
@@ -401,10 +531,15 @@ void JoinHip::_run(const size_t n, Meter &meter) {
         else
           ok = hk[i] == hbk[i] && h1[i] == f->second && h2[i] == hbv[i];
       }
-      if (!ok) {
-        std::cerr << "Incorrect results" << std::endl;
-        result->valid = false;
-      }
+    } else {  // the build keys are generated ascending and unique: binary search finds every probe row's partner
+      db_ok(dbhip_check_ujoin_u32(ak.get(), av.get(), n, bk.get(), bv.get(), n, ok_.get(), o1.get(), o2.get(), chk.dev(),
+                                  nullptr),
+            "dbhip_check_ujoin_u32");
+      ok = chk.get()[0] == 0;
+    }
+    if (!ok) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
     }
     meter.add_result(size_param(n), std::move(result));
   }
@@ -430,12 +565,17 @@ void GroupByLocalHip::_run(const size_t n, Meter &meter) {
   db_ok(dbhip_gen_uniform_u32(vals.get(), n, 43, 0, 1, 10000, nullptr), "gen vals");
   db_ok(dbhip_gen_uniform_u32(keys.get(), n, 42, 0, 0, groups - 1, nullptr), "gen keys");
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   std::vector<uint32_t> expected(groups, 0);
-  if (validate) {
+  CheckWords chk;
+  std::array<uint64_t, 4> want{};
+  if (host_check) {
     const auto hk = keys.to_host(n);
     const auto hv = vals.to_host(n);
     for (size_t i = 0; i < n; ++i) expected[hk[i]] = expected[hk[i]] + hv[i];
+  } else {  // sum of val * w(key) mod 2^32 for two weight functions, over the rows
+    db_ok(dbhip_check_weighted_sum_u32(keys.get(), vals.get(), n, chk.dev(), nullptr), "dbhip_check_weighted_sum_u32");
+    want = chk.get();
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -455,7 +595,16 @@ void GroupByLocalHip::_run(const size_t n, Meter &meter) {
     result->reduction_time = host_end - group_by_end;
     result->kernel_time = ev.elapsed();
     check_status(ws.get(), "GroupByLocalHip");
-    if (validate && out.to_host(groups) != expected) {
+    if (inject_fault()) poke_xor(out.get() + groups / 2, 1u);
+    bool ok;
+    if (host_check) {
+      ok = out.to_host(groups) == expected;
+    } else {  // ... and over (g, out[g]): equal iff every row's value reached its own group (mod 2^32, as the sums)
+      db_ok(dbhip_check_weighted_sum_u32(nullptr, out.get(), groups, chk.dev(), nullptr), "dbhip_check_weighted_sum_u32");
+      const auto g = chk.get();
+      ok = g[0] == want[0] && g[1] == want[1];
+    }
+    if (!ok) {
       std::cerr << "Incorrect results" << std::endl;
       result->valid = false;
     }
@@ -553,6 +702,90 @@ void HashBuildNonBitmaskHip::run(const RunOptions &opts) {
 void HashBuildNonBitmaskHip::init(const RunOptions &opts) { common_init(*this, opts); }
 
 // =====================================================================================================
+// ProbeHip — probe-only timing (probe/slab_probe.cpp:9-107: the table is built untimed, :38-62, the timed region is the
+// lookup kernel alone, :64-95, over the SAME unique keys that were inserted, so every lookup must hit, :100-103).
+// Table = the LDS-partitioned one-to-many table of dwarf 4a (DWARF_BENCH_PROBE_TABLE=bitmask: the bitmask-claimed
+// SimpleNonOwningHashTable instead); keys from the make_unique_random twin.  Isolates the probe's share of the join:
+// algorithmic bytes 4n (keys) + 8n (position, count).
+ProbeHip::ProbeHip() : Dwarf("ProbeHip") {}
+void ProbeHip::_run(const size_t n, Meter &meter) {
+  const RunOptions &opts = meter.opts();
+  banner("ProbeHip");
+  if (10ull * n > 0xFFFFFFFFull) fail("ProbeHip: keys are drawn from [0, 10*n) and must fit 32 bits");
+  const char *table_env = std::getenv("DWARF_BENCH_PROBE_TABLE");
+  const bool bitmask = table_env && std::string(table_env) == "bitmask";
+  DevBuf<uint32_t> keys(n), ids(n), pos(n), cnt(n);
+  db_ok(dbhip_gen_unique_sorted_u32(keys.get(), n, 11, 0, nullptr), "gen");  // slab_probe.cpp:17
+  const size_t ht_size = n ? 2 * n : 1;
+  const uint32_t seed = 421;
+  const size_t ws_bytes = bitmask ? dbhip_bitmask_table_workspace_bytes(ht_size) : dbhip_join_workspace_bytes(n);
+  DevBuf<unsigned char> ws(ws_bytes);
+  CheckWords chk;
+  Events ev;
+  for (size_t it = 0; it < opts.iterations; ++it) {
+    // build: untimed, a fresh table every iteration like the reference's AllocAdapter (:26-33)
+    if (bitmask) {
+      db_ok(dbhip_bitmask_table_reset(ws.get(), ws_bytes, ht_size, nullptr), "reset");
+      db_ok(dbhip_bitmask_table_insert_u32(keys.get(), keys.get(), n, ws.get(), ws_bytes, ht_size, 1, seed, 0, nullptr),
+            "dbhip_bitmask_table_insert_u32");
+    } else {
+      db_ok(dbhip_join_build_u32(keys.get(), n, ids.get(), ws.get(), ws_bytes, nullptr), "dbhip_join_build_u32");
+    }
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    auto result = std::make_unique<Result>();
+    const auto host_start = clk::now();
+    hip_ok(hipEventRecord(ev.a, nullptr), "event");
+    if (bitmask)
+      db_ok(dbhip_bitmask_table_lookup_u32(keys.get(), n, ws.get(), ht_size, 1, seed, pos.get(), cnt.get(), nullptr),
+            "dbhip_bitmask_table_lookup_u32");
+    else
+      db_ok(dbhip_join_probe_u32(keys.get(), n, ws.get(), n, pos.get(), cnt.get(), nullptr), "dbhip_join_probe_u32");
+    hip_ok(hipEventRecord(ev.b, nullptr), "event");
+    hip_ok(hipStreamSynchronize(nullptr), "sync");
+    const auto host_end = clk::now();
+    result->host_time = host_end - host_start;
+    result->kernel_time = ev.elapsed();
+    result->bytes = 12 * n;
+    if (n) check_status(ws.get(), "ProbeHip");
+    if (inject_fault() && n) poke_xor(cnt.get() + n / 2, 1u);
+    // slab_probe.cpp:36-37, :100-103: output == vector(n, 1) — every key found (once); the payload / the id the
+    // probe leads to must be the key's own
+    bool ok = true;
+    if (n <= validate_limit()) {
+      const auto hc = cnt.to_host(n), hp = pos.to_host(n);
+      ok = std::all_of(hc.begin(), hc.end(), [](uint32_t c) { return c == 1u; });
+      if (ok && bitmask) {
+        ok = hp == keys.to_host(n);  // payload = key
+      } else if (ok) {
+        const auto hi = ids.to_host(n);
+        for (size_t i = 0; i < n && ok; ++i) ok = hp[i] < n && hi[hp[i]] == i;
+      }
+    } else {  // sum of the counts == n with every count <= 1 is "all ones"; the join check covers both on the device
+      if (bitmask) {
+        db_ok(dbhip_check_sorted_u32(cnt.get(), n, 0, chk.dev(), nullptr), "dbhip_check_sorted_u32");
+        const auto g = chk.get();
+        ok = g[0] == 0 && g[2] == n;  // non-decreasing and summing to n over n entries that are 0 or 1
+      } else {
+        db_ok(dbhip_check_join_u32(keys.get(), n, keys.get(), n, pos.get(), cnt.get(), ids.get(), keys.get(), 0, 0, 0,
+                                   chk.dev(), nullptr),
+              "dbhip_check_join_u32");
+        const auto g = chk.get();
+        ok = g[0] == 0 && g[1] == n;
+      }
+    }
+    if (!ok) {
+      std::cerr << "Incorrect results" << std::endl;
+      result->valid = false;
+    }
+    meter.add_result(size_param(n), std::move(result));
+  }
+}
+void ProbeHip::run(const RunOptions &opts) {
+  for (auto size : opts.input_size) _run(size, meter());
+}
+void ProbeHip::init(const RunOptions &opts) { common_init(*this, opts); }
+
+// =====================================================================================================
 // ReduceHip — int sum of a column (reduce/reduce.cpp:27-98); expected = std::accumulate(..., 0) (:21).
 ReduceHip::ReduceHip() : Dwarf("ReduceHip") {}
 void ReduceHip::_run(const size_t n, Meter &meter) {
@@ -561,13 +794,17 @@ void ReduceHip::_run(const size_t n, Meter &meter) {
   DevBuf<int32_t> src(n), out(1);
   db_ok(dbhip_gen_uniform_u32(reinterpret_cast<uint32_t *>(src.get()), n, 42, 0, 1, 10000, nullptr), "gen");
   hip_ok(hipDeviceSynchronize(), "sync");
-  const bool validate = n <= validate_limit();
+  const bool host_check = n <= validate_limit();
   int32_t expected = 0;
-  if (validate) {
+  if (host_check) {
     const auto h = src.to_host(n);
     uint32_t acc = 0;  // accumulate with defined wrap-around; equals the int sum wherever that is defined
     for (int32_t v : h) acc += static_cast<uint32_t>(v);
     expected = static_cast<int32_t>(acc);
+  } else {  // the 64-bit key sum of the sortedness check's kernel, truncated: another code path over the same column
+    CheckWords chk;
+    db_ok(dbhip_check_sorted_u32(reinterpret_cast<uint32_t *>(src.get()), n, 0, chk.dev(), nullptr), "dbhip_check_sorted_u32");
+    expected = static_cast<int32_t>(static_cast<uint32_t>(chk.get()[2]));
   }
   Events ev;
   for (size_t it = 0; it < opts.iterations; ++it) {
@@ -582,7 +819,8 @@ void ReduceHip::_run(const size_t n, Meter &meter) {
     result->host_time = host_end - host_start;
     result->kernel_time = ev.elapsed();
     result->bytes = n * sizeof(int32_t);
-    if (validate && host_out != expected) {
+    if (inject_fault()) host_out ^= 1;
+    if (host_out != expected) {
       std::cerr << "Incorrect results" << std::endl;
       result->valid = false;
     }

@@ -6,7 +6,7 @@
 //   GroupByHip                    groupby/groupby.cpp:24-122
 //   JoinOmnisciHip                join/join_omnisci.cpp:49-118
 //   JoinHip                       join/join.cpp:8-154
-//   GroupByLocalHip, HashBuildHip, HashBuildNonBitmaskHip: the "next" rows of SURVEY 8(f)
+//   GroupByLocalHip, HashBuildHip, HashBuildNonBitmaskHip, ProbeHip: the "next" rows of SURVEY 8(f)
 #pragma once
 #include "dwarf_api.hpp"
 
@@ -32,6 +32,7 @@ DBHIP_DECLARE_DWARF(PartitionedJoinHip);      // radix-partitioned 
 DBHIP_DECLARE_DWARF(GroupByLocalHip);         // groupby/groupby_local.cpp:24-142 (two-phase timings, --executors)
 DBHIP_DECLARE_DWARF(HashBuildHip);            // hash/hash_build.cpp:8-98 (bitmask-claimed table, build only)
 DBHIP_DECLARE_DWARF(HashBuildNonBitmaskHip);  // hash/hash_build_non_bitmask.cpp:7-91 (CAS table, build only)
+DBHIP_DECLARE_DWARF(ProbeHip);                // probe/slab_probe.cpp:9-107 (table built untimed, lookups timed)
 DBHIP_DECLARE_DWARF(ReduceHip);               // reduce/reduce.cpp:27-98 (int sum)
 DBHIP_DECLARE_DWARF(NestedLoopJoinHip);       // join/nested_join.cpp:10-110 (dense cell matrix, small n)
 

@@ -17,6 +17,7 @@ void populate_registry() {
   registry->registerd(new GroupByLocalHip());
   registry->registerd(new HashBuildHip());
   registry->registerd(new HashBuildNonBitmaskHip());
+  registry->registerd(new ProbeHip());
   registry->registerd(new ReduceHip());
   registry->registerd(new NestedLoopJoinHip());
 #endif

@@ -12,7 +12,7 @@ import torch
 
 from . import _capi
 
-DEV_OK, DEV_SPIN_TIMEOUT, DEV_KEY_RANGE, DEV_TABLE_FULL = 0, 1, 2, 4
+DEV_OK, DEV_KEY_RANGE, DEV_TABLE_FULL = 0, 2, 4
 
 
 def _stream() -> int:
@@ -24,9 +24,17 @@ def _need(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
         raise ValueError(f"{name}: expected a contiguous {dtype} tensor on the GPU, got {t.dtype} on {t.device}")
 
 
+def _need16(t: torch.Tensor, name: str) -> None:
+    """radix sort and group-by read their columns with 16-byte loads (include/dbhip.h): a slice like t[1:] is refused"""
+    if t.numel() and t.data_ptr() % 16:
+        raise ValueError(f"{name}: the column must start on a 16-byte boundary (got offset {t.data_ptr() % 16}); "
+                         "copy the slice with .clone() first")
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
-    # torch's caching allocator hands out >= 512-byte aligned blocks; the C ABI asks for 256
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    # torch's caching allocator hands out >= 512-byte aligned blocks; the C ABI asks for 256.  Zeroed: an entry
+    # point that returns early (n == 0) must not leave an uninitialised status word behind.
+    return torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 def workspace_status(ws: torch.Tensor) -> int:
@@ -115,6 +123,7 @@ class RadixSort:
     def launch(self, keys: torch.Tensor, signed: bool = False) -> None:
         """Sorts `keys` (int32 storage) in place; signed=False orders the bits as uint32."""
         _need(keys, torch.int32, "keys")
+        _need16(keys, "keys")
         if keys.numel() != self.n:
             raise ValueError("size mismatch")
         fn = _capi.lib().dbhip_radix_sort_i32 if signed else _capi.lib().dbhip_radix_sort_u32
@@ -142,6 +151,8 @@ class GroupBySum:
     def launch(self, keys: torch.Tensor, vals: torch.Tensor) -> None:
         _need(keys, torch.int32, "keys")
         _need(vals, torch.int32, "vals")
+        _need16(keys, "keys")
+        _need16(vals, "vals")
         if keys.numel() != self.n or vals.numel() != self.n:
             raise ValueError("size mismatch")
         _capi.check(_capi.lib().dbhip_groupby_sum_u32(keys.data_ptr(), vals.data_ptr(), self.n, self.groups,
@@ -152,6 +163,8 @@ class GroupBySum:
         """phase 1 of groupby/groupby_local.cpp:52-83: privatised partial sums; 0 = let the library choose"""
         _need(keys, torch.int32, "keys")
         _need(vals, torch.int32, "vals")
+        _need16(keys, "keys")
+        _need16(vals, "vals")
         if keys.numel() != self.n or vals.numel() != self.n:
             raise ValueError("size mismatch")
         _capi.check(_capi.lib().dbhip_groupby_partial_u32(keys.data_ptr(), vals.data_ptr(), self.n, self.groups,
@@ -207,6 +220,18 @@ class HashJoin:
     def result(self):
         _check_status(self.ws, "join")
         return self.pos[: self.np], self.cnt[: self.np], self.ids[: self.nb]
+
+
+def join_answers(ids: torch.Tensor, pos: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
+    """(n_probe, 2) int64: the reference's JoinOneToMany records {device pointer into ids, size}
+    (common/dpcpp/omnisci_hashtable.hpp:12-17)"""
+    _need(ids, torch.int32, "ids")
+    _need(pos, torch.int32, "pos")
+    _need(cnt, torch.int32, "cnt")
+    out = torch.empty((max(pos.numel(), 1), 2), dtype=torch.int64, device=pos.device)
+    _capi.check(_capi.lib().dbhip_join_answers_u32(ids.data_ptr(), pos.data_ptr(), cnt.data_ptr(), pos.numel(),
+                                                   out.data_ptr(), _stream()), "join_answers_u32")
+    return out[: pos.numel()]
 
 
 def hash_join(build_keys: torch.Tensor, probe_keys: torch.Tensor):
@@ -338,3 +363,111 @@ class BitmaskTable:
         """the payload array of the table (for slot-level known-answer tests)"""
         off = 256 + 4 * self.size
         return self.ws[off: off + 4 * self.size].view(torch.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# exclusive prefix sum (scan/scan.cl:44-66, tests/scan_tests.cpp:14-21, dpl_wrapper.hpp:18-25)
+# ---------------------------------------------------------------------------------------------
+def exclusive_scan(src: torch.Tensor, init: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[0] = init, out[i] = init + src[0] + ... + src[i-1] (uint32 wrap-around); out may be src"""
+    _need(src, torch.int32, "src")
+    n = src.numel()
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=src.device)[:n]
+    _need(out, torch.int32, "out")
+    lib = _capi.lib()
+    ws_bytes = lib.dbhip_exclusive_scan_u32_workspace_bytes(n)
+    ws = _ws(ws_bytes, src.device)
+    _capi.check(lib.dbhip_exclusive_scan_u32(src.data_ptr(), n, init & 0xFFFFFFFF, out.data_ptr(), ws.data_ptr(), ws_bytes,
+                                             _stream()), "exclusive_scan_u32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side validators (what the ...Hip dwarfs use for Result::valid at large sizes)
+# ---------------------------------------------------------------------------------------------
+def _result(words: int, device) -> torch.Tensor:
+    return torch.empty(words, dtype=torch.int64, device=device)
+
+
+def _u64(t: torch.Tensor):
+    return [int(x) & 0xFFFFFFFFFFFFFFFF for x in t.cpu().tolist()]
+
+
+def check_fingerprint_lt(src: torch.Tensor, filter_value: int):
+    """-> (fingerprint, length) of the subsequence of src with x < filter_value, order-sensitive"""
+    _need(src, torch.int32, "src")
+    lib = _capi.lib()
+    ws_bytes = lib.dbhip_check_fingerprint_workspace_bytes(src.numel())
+    ws = _ws(ws_bytes, src.device)
+    res = _result(2, src.device)
+    _capi.check(lib.dbhip_check_fingerprint_lt_i32(src.data_ptr(), src.numel(), filter_value, res.data_ptr(), ws.data_ptr(),
+                                                   ws_bytes, _stream()), "check_fingerprint_lt_i32")
+    return tuple(_u64(res))
+
+
+def check_sorted(keys: torch.Tensor, signed: bool = False):
+    """-> (descents, multiset fingerprint, key sum)"""
+    _need(keys, torch.int32, "keys")
+    res = _result(3, keys.device)
+    _capi.check(_capi.lib().dbhip_check_sorted_u32(keys.data_ptr(), keys.numel(), int(signed), res.data_ptr(), _stream()),
+                "check_sorted_u32")
+    return tuple(_u64(res))
+
+
+def check_weighted_sum(keys: torch.Tensor | None, vals: torch.Tensor):
+    """-> two 32-bit weighted sums of vals, weights drawn from keys (None: the index)"""
+    _need(vals, torch.int32, "vals")
+    if keys is not None:
+        _need(keys, torch.int32, "keys")
+    res = _result(2, vals.device)
+    _capi.check(_capi.lib().dbhip_check_weighted_sum_u32(keys.data_ptr() if keys is not None else None, vals.data_ptr(),
+                                                         vals.numel(), res.data_ptr(), _stream()), "check_weighted_sum_u32")
+    return tuple(_u64(res))
+
+
+def check_permutation(ids: torch.Tensor) -> int:
+    """-> number of entries that are out of range or repeated (0 iff ids is a permutation of 0..n-1)"""
+    _need(ids, torch.int32, "ids")
+    lib = _capi.lib()
+    ws_bytes = lib.dbhip_check_permutation_workspace_bytes(ids.numel())
+    ws = _ws(ws_bytes, ids.device)
+    res = _result(1, ids.device)
+    _capi.check(lib.dbhip_check_permutation_u32(ids.data_ptr(), ids.numel(), res.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                _stream()), "check_permutation_u32")
+    return _u64(res)[0]
+
+
+def check_join(sorted_build: torch.Tensor, probe: torch.Tensor, pos: torch.Tensor, cnt: torch.Tensor, ids: torch.Tensor,
+               build_keys: torch.Tensor | None = None, gen=(0, 0, 0)):
+    """-> (bad probe rows, sum of counts); build_keys None: ids are global row ids of gen = (seed, lo, hi)"""
+    for t, name in ((sorted_build, "sorted_build"), (probe, "probe"), (pos, "pos"), (cnt, "cnt"), (ids, "ids")):
+        _need(t, torch.int32, name)
+    res = _result(2, probe.device)
+    _capi.check(_capi.lib().dbhip_check_join_u32(sorted_build.data_ptr(), sorted_build.numel(), probe.data_ptr(),
+                                                 probe.numel(), pos.data_ptr(), cnt.data_ptr(), ids.data_ptr(),
+                                                 build_keys.data_ptr() if build_keys is not None else None,
+                                                 gen[0], gen[1], gen[2], res.data_ptr(), _stream()), "check_join_u32")
+    return tuple(_u64(res))
+
+
+def check_ujoin(sorted_build: torch.Tensor, build_vals: torch.Tensor, probe: torch.Tensor, probe_vals: torch.Tensor,
+                out_key: torch.Tensor, out_bval: torch.Tensor, out_pval: torch.Tensor):
+    """-> (bad probe rows, hits)"""
+    res = _result(2, probe.device)
+    _capi.check(_capi.lib().dbhip_check_ujoin_u32(sorted_build.data_ptr(), build_vals.data_ptr(), sorted_build.numel(),
+                                                  probe.data_ptr(), probe_vals.data_ptr(), probe.numel(),
+                                                  out_key.data_ptr(), out_bval.data_ptr(), out_pval.data_ptr(),
+                                                  res.data_ptr(), _stream()), "check_ujoin_u32")
+    return tuple(_u64(res))
+
+
+def check_gen_uniform(values: torch.Tensor, seed: int, lo: int, hi: int, first_index: int = 0,
+                      indices: torch.Tensor | None = None) -> int:
+    """-> number of values that differ from lo + mix64(seed, index) % (hi - lo + 1)"""
+    _need(values, torch.int32, "values")
+    res = _result(1, values.device)
+    _capi.check(_capi.lib().dbhip_check_gen_uniform_u32(values.data_ptr(), indices.data_ptr() if indices is not None else None,
+                                                        values.numel(), seed, first_index, lo, hi, res.data_ptr(),
+                                                        _stream()), "check_gen_uniform_u32")
+    return _u64(res)[0]

@@ -4,7 +4,8 @@ RCCL/xGMI).  No reference counterpart — the reference is single-device; SURVEY
 Per rank, with local shards of the build (R) and probe (S) key columns and their global row offsets:
   1. partition  both shards by destination GPU = mixed hash of the key (dbhip_pjoin_partition_u32):
                 bucket-major (key, global row id) pairs + per-bucket counts;
-  2. counts     one all_to_all of the P-entry count vectors (who sends how much to whom);
+  2. counts     one all_gather of the P-entry count vectors: every rank holds the P x P matrix (who sends how much to
+                whom), hence its receive sizes and — identically on all ranks — the number of exchange rounds;
   3. exchange   all_to_all of the pairs (RCCL: every GPU sends 1/P of its rows to each peer, one peer per
                 xGMI link, all links busy at once), one collective per column (keys, row ids);
   4. local join dwarf 4a on the received pairs (dbhip_join_build_pairs_u32 / dbhip_join_probe_u32): the id
@@ -17,7 +18,7 @@ The steps of the two relations are interleaved so that the xGMI exchange hides b
     compute stream :  partition R |            partition S | build R            | probe S
     RCCL stream    :          counts R | exchange R | counts S | exchange S |
 
-The host blocks twice, on the two tiny count exchanges (split sizes must be host integers).
+The host blocks twice, on the two tiny count gathers (split sizes must be host integers).
 
 The compute steps go through a small backend object so that the orchestration (split sizes, collectives,
 bookkeeping) can be exercised on CPU/gloo in tests with a test-only backend; the product backend is
@@ -53,6 +54,11 @@ class HipBackend:
     def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None):
         return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
 
+    def column_sum(self, col: torch.Tensor) -> int:
+        """wrap-around (mod 2^32) sum of a column, on the device (dbhip_reduce_sum_i32)"""
+        from . import ops
+        return int(ops.reduce_sum(col).item()) & 0xFFFFFFFF if col.numel() else 0
+
 
 @dataclass
 class PartitionedJoinResult:
@@ -65,7 +71,15 @@ class PartitionedJoinResult:
     recv_probe_rows: int
 
 
-_MAX_MESSAGE_BYTES = 1 << 31
+# Largest single message (one peer's segment of one column) the exchange hands to the backend, in ELEMENTS.
+# What is known: one ncclSend/ncclRecv pair of exactly 2^29 uint32 (2 GiB) through RCCL 2.27.7 completed without
+# an error and delivered garbage (PartitionedJoinHip --gpus 1 at 2^30 rows, caught by its conservation check);
+# pieces of 2^28 elements (1 GiB) have carried every run since.  The cause inside RCCL was not established — a
+# byte count that no longer fits 31 bits is the obvious suspect — so the bound is set where the evidence is:
+# no message above 1 GiB.  A hash bucket of 2^30 rows over 2 ranks holds 2^28 +- ~12K rows, i.e. about half of
+# them are just above 1 GiB: such a segment goes out in two rounds.  Both sides derive the rounds from the same
+# split sizes, so the r-th piece sent to a peer meets the r-th piece received from it.
+MAX_MESSAGE_ELEMS = 1 << 28
 
 
 class _Done:
@@ -79,50 +93,117 @@ class _Done:
 
 
 class _Pending:
-    """handle of a collective in flight on the backend's own stream; wait() orders the current stream after it"""
+    """handle of collectives in flight on the backend's own stream; wait() orders the current stream after them and,
+    when the exchange was cut into rounds, moves every round's pieces to their place in the output"""
 
-    def __init__(self, work, out, keep):
-        self.work, self.out, self.keep = work, out, keep  # `keep`: the send buffer must outlive the collective
+    def __init__(self, rounds, out, keep):
+        self.rounds, self.out, self.keep = rounds, out, keep  # `keep`: send buffers must outlive the collectives
 
     def wait(self):
-        self.work.wait()
-        self.keep = None
+        for work, stage, pieces in self.rounds:
+            work.wait()
+            if stage is not None:
+                at = 0
+                for dst_off, length in pieces:
+                    self.out[dst_off: dst_off + length].copy_(stage[at: at + length])
+                    at += length
+        self.rounds, self.keep = [], None
         return self.out
 
 
-def _a2a(inp: torch.Tensor, out_splits, in_splits, group):
-    """all_to_all_single -> handle.  With the nccl (= RCCL) backend this is one async collective on device
-    memory over xGMI.  A gloo group (CPU rehearsal of the exchange) only moves host memory, so device tensors
-    are staged through the host there, synchronously."""
-    n_out = int(sum(out_splits)) if out_splits is not None else inp.numel()
+def _offsets(splits):
+    off, acc = [], 0
+    for x in splits:
+        off.append(acc)
+        acc += int(x)
+    return off
+
+
+def _a2a(inp: torch.Tensor, out_splits, in_splits, group, largest: int, max_elems: int | None = None):
+    """all_to_all_single -> handle.  `largest` = the largest segment between ANY two ranks (from the gathered count
+    matrix): the number of rounds must be the same on every rank of the collective.  With the nccl (= RCCL) backend
+    these are async collectives on device memory over xGMI.  A gloo group (CPU rehearsal of the exchange) only moves host memory, so device tensors are staged
+    through the host there, synchronously.  No message exceeds `max_elems` elements (default MAX_MESSAGE_ELEMS):
+    larger segments are sent in rounds, round r carrying elements [r*max, (r+1)*max) of every peer's segment."""
+    max_elems = int(max_elems or MAX_MESSAGE_ELEMS)
     inp = inp.contiguous()
-    # one send/recv of 2 GiB or more was measured to deliver garbage without an error through RCCL 2.27.7
-    # (PartitionedJoinHip, which therefore cuts its messages into 1 GiB pieces); torch's all_to_all_single cannot be
-    # cut from here, so refuse instead of corrupting: 2^30 x 2^30 over >= 2 ranks needs 1 GiB per message at most
-    biggest = max(list(out_splits or [0]) + list(in_splits or [0]) + [0]) * inp.element_size()
-    if biggest >= _MAX_MESSAGE_BYTES:
-        raise ValueError(f"a {biggest} byte message to one peer exceeds the {_MAX_MESSAGE_BYTES} byte limit of the exchange")
-    if inp.is_cuda and dist.get_backend(group) == "gloo":
-        host_out = torch.empty(n_out, dtype=inp.dtype)
-        dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-        return _Done(host_out.to(inp.device))
-    out = torch.empty(n_out, dtype=inp.dtype, device=inp.device)
-    work = dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
-                                  async_op=True)
-    return _Pending(work, out, inp)
+    out_splits, in_splits = [int(x) for x in out_splits], [int(x) for x in in_splits]
+    n_out = sum(out_splits)
+    n_rounds = max(1, -(-int(largest) // max_elems))
+    staged_on_host = inp.is_cuda and dist.get_backend(group) == "gloo"
+    src = inp.cpu() if staged_on_host else inp
+    out = torch.empty(n_out, dtype=inp.dtype, device=src.device)
+    if n_rounds == 1:
+        if staged_on_host:
+            dist.all_to_all_single(out, src, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+            return _Done(out.to(inp.device))
+        work = dist.all_to_all_single(out, src, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                      async_op=True)
+        return _Pending([(work, None, None)], out, src)
+    in_off, out_off = _offsets(in_splits), _offsets(out_splits)
+    rounds, keep = [], [src]
+    for r in range(n_rounds):
+        lo = r * max_elems
+        send_len = [max(0, min(max_elems, n - lo)) for n in in_splits]
+        recv_len = [max(0, min(max_elems, n - lo)) for n in out_splits]
+        send = torch.cat([src[in_off[q] + lo: in_off[q] + lo + send_len[q]] for q in range(len(in_splits))])
+        stage = torch.empty(sum(recv_len), dtype=inp.dtype, device=src.device)
+        pieces = [(out_off[q] + lo, recv_len[q]) for q in range(len(out_splits))]
+        work = dist.all_to_all_single(stage, send, output_split_sizes=recv_len, input_split_sizes=send_len, group=group,
+                                      async_op=not staged_on_host)
+        keep.append(send)
+        if staged_on_host:
+            rounds.append((_Done(None), stage, pieces))
+        else:
+            rounds.append((work, stage, pieces))
+    handle = _Pending(rounds, out, keep)
+    if staged_on_host:
+        return _Done(handle.wait().to(inp.device))
+    return handle
 
 
 def _exchange_counts(counts: torch.Tensor, group):
-    """counts: this rank's P send counts (device or host int64/uint64).  One tiny all_to_all tells every rank what
-    it will receive.  -> (send, recv) as host int lists — blocks the host until `counts` is computed and exchanged."""
+    """counts: this rank's P send counts (device or host int64/uint64).  One tiny all_gather gives every rank the
+    whole P x P count matrix (row = sender): what it will receive, and — the same on every rank — the largest
+    segment anywhere, from which all ranks derive the same number of exchange rounds.
+    -> (send, recv, largest) as host ints — blocks the host until `counts` is computed and gathered."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     send = counts.to(torch.int64)
-    recv = _a2a(send, None, None, group).wait()
-    return [int(x) for x in send.cpu().tolist()], [int(x) for x in recv.cpu().tolist()]
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        send = send.cpu()
+    rows = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(rows, send, group=group)
+    matrix = torch.stack(rows).cpu()
+    return ([int(x) for x in matrix[rank].tolist()], [int(x) for x in matrix[:, rank].tolist()], int(matrix.max().item()))
+
+
+class ExchangeError(RuntimeError):
+    """the all-to-all did not deliver what was sent"""
+
+
+def _verify_exchange(backend, sent_cols, recv_cols, group) -> None:
+    """Conservation check of the exchange (the C++ dwarf's always-on check, hip_dwarfs.cpp): the wrap-around sums of
+    the four columns over everything SENT by all ranks equal the sums over everything RECEIVED by all ranks.  One
+    all_reduce of 8 words; raises ExchangeError on every rank when a column was not conserved."""
+    sums = torch.tensor([backend.column_sum(t) for t in list(sent_cols) + list(recv_cols)], dtype=torch.int64)
+    dev = sent_cols[0].device
+    if dist.get_backend(group) != "gloo":
+        sums = sums.to(dev)
+    dist.all_reduce(sums, group=group)
+    tot = [int(x) & 0xFFFFFFFF for x in sums.cpu().tolist()]
+    bad = [c for c in range(4) if tot[c] != tot[4 + c]]
+    if bad:
+        raise ExchangeError(f"the exchange did not conserve column(s) {bad} (0/1 = build key / row id, 2/3 = probe): "
+                            f"sent sums {tot[:4]}, received sums {tot[4:]}")
 
 
 def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_first_row: int, probe_first_row: int,
-                     group=None, backend=None) -> PartitionedJoinResult:
-    """Join this rank's shards; collective over `group` (default: WORLD).  World size 1 = plain local join."""
+                     group=None, backend=None, verify_exchange: bool = True,
+                     max_message_elems: int | None = None) -> PartitionedJoinResult:
+    """Join this rank's shards; collective over `group` (default: WORLD).  World size 1 = plain local join.
+    verify_exchange: run the conservation check after the join (a few column reductions + one tiny all_reduce;
+    benchmarks switch it off for the timed steps and keep it on for the warm-up ones)."""
     backend = backend or HipBackend()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -135,18 +216,20 @@ def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_f
 
     # R: partition, learn the split sizes, start its exchange
     rk, rr, rc = backend.partition(build_keys, build_first_row, world)
-    r_send, r_recv = _exchange_counts(rc, group)
-    rk_x = _a2a(rk, r_recv, r_send, group)
-    rr_x = _a2a(rr, r_recv, r_send, group)
+    r_send, r_recv, r_big = _exchange_counts(rc, group)
+    rk_x = _a2a(rk, r_recv, r_send, group, r_big, max_message_elems)
+    rr_x = _a2a(rr, r_recv, r_send, group, r_big, max_message_elems)
     # S: partition while R is on the links
     sk, sr, sc = backend.partition(probe_keys, probe_first_row, world)
-    s_send, s_recv = _exchange_counts(sc, group)
-    sk_x = _a2a(sk, s_recv, s_send, group)
-    sr_x = _a2a(sr, s_recv, s_send, group)
+    s_send, s_recv, s_big = _exchange_counts(sc, group)
+    sk_x = _a2a(sk, s_recv, s_send, group, s_big, max_message_elems)
+    sr_x = _a2a(sr, s_recv, s_send, group, s_big, max_message_elems)
     # build on the received R pairs while S is on the links, then probe
     rk_in, rr_in = rk_x.wait(), rr_x.wait()
     plan = backend.build(rk_in, rr_in, int(sum(s_recv)))
     sk_in, sr_in = sk_x.wait(), sr_x.wait()
     pos, cnt, ids_global = backend.probe(plan, sk_in)
+    if verify_exchange:
+        _verify_exchange(backend, (rk, rr, sk, sr), (rk_in, rr_in, sk_in, sr_in), group)
     sent = int(sum(r_send) - r_send[rank] + sum(s_send) - s_send[rank])
     return PartitionedJoinResult(sr_in, pos, cnt, ids_global, sent, rk_in.numel(), sk_in.numel())

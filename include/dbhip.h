@@ -32,6 +32,9 @@
  *   dbhip_nested_join_u32     join/nested_join.cpp:52-66
  *   dbhip_pjoin_*             no reference counterpart (multi-GPU radix-partitioned join)
  *   dbhip_gen_*               common/common.hpp:31-40, common/common.cpp:7-20 (data generators)
+ *   dbhip_exclusive_scan_u32  scan/scan.cl:44-66, tests/scan_tests.cpp:14-21, dpl_wrapper.hpp:18-25 (exclusive_scan)
+ *   dbhip_check_*             the dwarfs' own result checks (scan/scan.cpp:157-164, sort/radix.cpp:46-52,
+ *                             groupby/groupby.cpp:95-103, join/join_omnisci.cpp:31-45, join/join.cpp:133-137)
  */
 #ifndef DBHIP_H
 #define DBHIP_H
@@ -53,8 +56,7 @@ extern "C" {
 
 /* device-side status word values (dbhip_workspace_status) */
 #define DBHIP_DEV_OK 0u
-#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* reserved: no kernel of this library waits on another workgroup any more */
-#define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count */
+#define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count, or the 0xFFFFFFFF sentinel as a join build key */
 #define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
 
 typedef void *dbhip_stream_t; /* hipStream_t */
@@ -67,7 +69,7 @@ int dbhip_device_info(int device, char *name, size_t len, int *compute_units, in
  * then synchronises `stream`.  Convenience for hosts that have no other D2H path. */
 int dbhip_workspace_status(const void *workspace, uint32_t *host_status, dbhip_stream_t stream);
 
-/* ---- deterministic synthetic data (counter-based; oracle/dbo_gen.c is the CPU twin) ---------
+/* ---- deterministic synthetic data (counter-based; oracle/dbo.c dbo_gen_uniform_u32 / dbo_gen_unique_sorted_u32 are the CPU twins) ---------
  * element i of the logical column = lo + mix64(seed, first_index + i) % (hi - lo + 1)            */
 int dbhip_gen_uniform_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t first_index,
                           uint32_t lo, uint32_t hi, dbhip_stream_t stream);
@@ -89,7 +91,8 @@ int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int
 /* ---- dwarf 2: LSD radix sort ---------------------------------------------------------------
  * Ascending sort of n 32-bit keys.  keys is sorted IN PLACE; tmp is an n-element ping-pong buffer.
  * radix_bits in {4, 8}: digit width of every pass (4 = the configuration named in BASELINE.json,
- * 8 = the tuned variant).  Passes whose digit is constant over the whole input are skipped.      */
+ * 8 = the tuned variant).  Passes whose digit is constant over the whole input are skipped.
+ * keys and tmp must be 16-byte aligned (DBHIP_EINVAL otherwise).                                   */
 size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits);
 int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
@@ -100,7 +103,8 @@ int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits, 
 /* ---- dwarf 3: group-by hash aggregate, SUM ------------------------------------------------------
  * out[g] = sum of vals[i] over rows with keys[i] == g (uint32 wrap-around), g in [0, groups).
  * Keys must be < groups (the reference's dense output[key] contract, groupby/groupby.cpp:88-91);
- * a larger key sets DBHIP_DEV_KEY_RANGE and is ignored.                                           */
+ * a larger key sets DBHIP_DEV_KEY_RANGE and is ignored.  keys and vals must be 16-byte aligned
+ * (DBHIP_EINVAL otherwise); the scan, reduce and exclusive-scan entry points take any 4-byte aligned column. */
 size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t groups);
 int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t groups,
                           uint32_t *out, void *workspace, size_t workspace_bytes,
@@ -122,7 +126,8 @@ int dbhip_groupby_merge_u32(uint32_t groups, uint32_t max_private_tables, uint32
  * defined, as in the reference).  Probe: per probe row i, out_count[i] = number of build rows with
  * the same key and out_pos[i] = offset of their ids (0/0 on a miss).
  * 0xFFFFFFFF is the empty-slot sentinel and must not occur as a key
- * (join/join_omnisci.cpp:52).  The table lives in the workspace between build and probe; the
+ * (join/join_omnisci.cpp:52): a build row carrying it sets DBHIP_DEV_KEY_RANGE and is dropped, a probe row
+ * carrying it gets 0/0.  The table lives in the workspace between build and probe; the
  * probe takes n_build again because the table geometry is a pure function of it.               */
 size_t dbhip_join_workspace_bytes(size_t n_build);
 int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids, void *workspace,
@@ -135,6 +140,16 @@ int dbhip_join_build_pairs_u32(const uint32_t *build_keys, const uint32_t *build
 int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void *workspace,
                          size_t n_build, uint32_t *out_pos, uint32_t *out_count,
                          dbhip_stream_t stream);
+
+/* The reference's answer record (JoinOneToMany<global_ptr<size_t>>, common/dpcpp/omnisci_hashtable.hpp:12-17: pointer
+ * into the id buffer + number of ids) for callers that want that shape instead of two 32-bit columns:
+ * answers[i] = {ids + out_pos[i], out_count[i]} (a miss: {ids, 0}).  16 bytes per probe row.          */
+typedef struct dbhip_join_one_to_many {
+  const uint32_t *vals;
+  size_t size;
+} dbhip_join_one_to_many;
+int dbhip_join_answers_u32(const uint32_t *ids, const uint32_t *out_pos, const uint32_t *out_count, size_t n_probe,
+                           dbhip_join_one_to_many *answers, dbhip_stream_t stream);
 
 /* ---- dwarf 4b: unique-key join carrying payloads (Join semantics, join/join.cpp:60-104) ---------
  * Build keys are unique.  For probe row i: on a hit out_key[i] = key, out_build_val[i] = payload of
@@ -188,6 +203,62 @@ int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, dbhip_strea
 int dbhip_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, const uint32_t *b_keys,
                           const uint32_t *b_vals, size_t n_a, size_t n_b, uint32_t *out_key,
                           uint32_t *out_val1, uint32_t *out_val2, dbhip_stream_t stream);
+
+/* ---- exclusive prefix sum -------------------------------------------------------
+ * dst[0] = init, dst[i] = init + src[0] + ... + src[i-1], uint32 wrap-around: the semantics of the reference's
+ * prefix_sum_scalar / prefix_local_test (tests/scan_tests.cpp:14-21, :46-51, scan/scan.cl:44-66) and of
+ * oneDPL exclusive_scan behind DPLWrapper::exclusive_scan (common/dpcpp/dpl_wrapper/dpl_wrapper.hpp:18-25,
+ * used by common/dpcpp/omnisci_hashtable.hpp:252-254).  dst may alias src.                             */
+size_t dbhip_exclusive_scan_u32_workspace_bytes(size_t n);
+int dbhip_exclusive_scan_u32(const uint32_t *src, size_t n, uint32_t init, uint32_t *dst, void *workspace,
+                             size_t workspace_bytes, dbhip_stream_t stream);
+
+/* ---- device-side validators: Result::valid of the `...Hip` dwarfs above the host-check size -------------
+ * Each is an algorithm independent of the kernel it checks; `result` is a DEVICE array of uint64 words,
+ * zeroed by the call.  Reference checks replaced: scan/scan.cpp:157-164 (out == std::copy_if),
+ * sort/radix.cpp:46-52 (== std::sort), groupby/groupby.cpp:95-103 (== expected_GroupBy),
+ * join/join_omnisci.cpp:31-45 (are_equal: size per probe row + membership of every id),
+ * join/join.cpp:133-137 (== seq_join).
+ *   fingerprint_lt_i32  result[0] = order-sensitive fingerprint of the subsequence x < filter_value,
+ *                       result[1] = its length.  copy_if is right iff the pair computed over src equals the
+ *                       pair computed over out[0..out_size) (every element of out passes the same filter).
+ *   sorted_u32          result[0] = number of i with key[i] > key[i+1] (signed_order != 0: as int32),
+ *                       result[1], result[2] = commutative multiset fingerprint (compare with the input's).
+ *   weighted_sum_u32    result[0], result[1] = sum vals[i] * w(keys[i]) mod 2^32 for two weight functions;
+ *                       keys == NULL means keys[i] = i (the dense group-by output).
+ *   permutation_u32     result[0] = number of entries >= n or seen before (0 iff ids is a permutation of 0..n-1).
+ *   join_u32            sorted_build_keys = the build column sorted ascending.  result[0] = number of probe rows
+ *                       whose count differs from the key's multiplicity in the build column, whose id range
+ *                       leaves the id buffer, or whose first / last / one pseudo-random id does not carry the key;
+ *                       result[1] = sum of all counts.  build_keys != NULL: ids are build row indices and the key
+ *                       of id is build_keys[id]; build_keys == NULL: ids are global row ids of a generated column
+ *                       and the key of id is gen_lo + mix64(gen_seed, id) % (gen_hi - gen_lo + 1).
+ *   ujoin_u32           build keys unique and sorted ascending (what dbhip_gen_unique_sorted_u32 produces):
+ *                       result[0] = probe rows whose (key, build payload, probe payload) triple or sentinels are
+ *                       wrong, result[1] = number of hits.
+ *   gen_uniform_u32     result[0] = number of i with values[i] != lo + mix64(seed, index_i) % (hi - lo + 1),
+ *                       index_i = indices ? indices[i] : first_index + i.                              */
+size_t dbhip_check_fingerprint_workspace_bytes(size_t n);
+int dbhip_check_fingerprint_lt_i32(const int32_t *src, size_t n, int32_t filter_value, uint64_t *result,
+                                   void *workspace, size_t workspace_bytes, dbhip_stream_t stream);
+int dbhip_check_sorted_u32(const uint32_t *keys, size_t n, int signed_order, uint64_t *result,
+                           dbhip_stream_t stream);
+int dbhip_check_weighted_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n, uint64_t *result,
+                                 dbhip_stream_t stream);
+size_t dbhip_check_permutation_workspace_bytes(size_t n);
+int dbhip_check_permutation_u32(const uint32_t *ids, size_t n, uint64_t *result, void *workspace,
+                                size_t workspace_bytes, dbhip_stream_t stream);
+int dbhip_check_join_u32(const uint32_t *sorted_build_keys, size_t n_build, const uint32_t *probe_keys,
+                         size_t n_probe, const uint32_t *out_pos, const uint32_t *out_count, const uint32_t *ids,
+                         const uint32_t *build_keys, uint64_t gen_seed, uint32_t gen_lo, uint32_t gen_hi,
+                         uint64_t *result, dbhip_stream_t stream);
+int dbhip_check_ujoin_u32(const uint32_t *sorted_build_keys, const uint32_t *build_vals, size_t n_build,
+                          const uint32_t *probe_keys, const uint32_t *probe_vals, size_t n_probe,
+                          const uint32_t *out_key, const uint32_t *out_build_val, const uint32_t *out_probe_val,
+                          uint64_t *result, dbhip_stream_t stream);
+int dbhip_check_gen_uniform_u32(const uint32_t *values, const uint32_t *indices, size_t n, uint64_t seed,
+                                uint64_t first_index, uint32_t lo, uint32_t hi, uint64_t *result,
+                                dbhip_stream_t stream);
 
 #ifdef __cplusplus
 }

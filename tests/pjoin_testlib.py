@@ -51,6 +51,21 @@ class OracleBackend:
     def local_join(self, build_keys, probe_keys, build_row_ids=None):
         return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
 
+    def column_sum(self, col):
+        return int(col.numpy().view(np.uint32).astype(np.uint64).sum()) & 0xFFFFFFFF
+
+
+class LossyBackend(OracleBackend):
+    """reports a wrong sum for one received column on rank 1: the conservation check must notice"""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, 0
+
+    def column_sum(self, col):
+        self.calls += 1
+        s = super().column_sum(col)
+        return (s + 1) & 0xFFFFFFFF if (self.rank == 1 and self.calls == 6) else s
+
 
 def check_global(results, build_all: np.ndarray, probe_all: np.ndarray):
     """results: list over ranks of (probe_row_ids, pos, cnt, build_row_ids) numpy uint32 arrays.

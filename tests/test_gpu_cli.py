@@ -17,7 +17,7 @@ def _run(args, **kw):
 
 
 @pytest.mark.parametrize("dwarf", ["TwoPassScanHip", "DPLScanHip", "RadixHip", "JoinOmnisciHip", "JoinHip",
-                                   "HashBuildHip", "HashBuildNonBitmaskHip", "ReduceHip", "NestedLoopJoinHip"])
+                                   "HashBuildHip", "HashBuildNonBitmaskHip", "ProbeHip", "ReduceHip", "NestedLoopJoinHip"])
 def test_dwarf_suite(dwarf):
     r = _run([dwarf, "--device=hip", "--iterations", "10", "--input_size"] + SIZES)
     assert r.returncode == 0, r.stderr
@@ -91,10 +91,74 @@ def test_large_sizes_through_cli():
 
 
 def test_library_usage_example():
-    """the README / example/bench_usage flow through DwarfBench::makeMeasurements with DeviceType::HIP"""
-    r = subprocess.run([str(LIB / "bench_usage")], capture_output=True, text=True, timeout=300)
+    """the library API (DwarfBench::makeMeasurements with DeviceType::HIP) through examples/hip_library_usage.cpp"""
+    r = subprocess.run([str(LIB / "hip_library_usage")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     lines = [l for l in r.stdout.splitlines() if "RESULT:" in l]
     assert len(lines) == 4 * 10  # 4 dwarfs x 10 iterations
     assert all(l.split()[3] == "1024" for l in lines)
     assert "ncorrect results" not in r.stderr
+
+
+# ---- Result::valid at BASELINE sizes: device-side validators, and proof that they can fail ------------------------
+BIG = [("TwoPassScanHip", "268435456", []), ("RadixHip", "16777216", []),
+       ("GroupByHip", "67108864", ["--groups_count", "65536"]), ("JoinOmnisciHip", "67108864", []),
+       ("JoinHip", "67108864", []), ("ProbeHip", "67108864", []), ("ReduceHip", "268435456", [])]
+
+
+@pytest.mark.parametrize("dwarf,size,extra", BIG)
+def test_valid_is_computed_at_baseline_sizes(dwarf, size, extra):
+    """scan/scan.cpp:157-164 validates every iteration at every size; above DWARF_BENCH_VALIDATE_MAX the HIP dwarfs
+    do it with the device-side validators (forced here for every size above 2^20 so the sort is covered as well)"""
+    import os
+    env = {**os.environ, "DWARF_BENCH_VALIDATE_MAX": "1048576"}
+    r = _run([dwarf, "--device=hip", "--iterations", "2", "--input_size", size] + extra, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 2
+
+
+@pytest.mark.parametrize("limit", ["1048576", "1"])  # host-side checks / device-side validators
+@pytest.mark.parametrize("dwarf,extra", [("TwoPassScanHip", []), ("DPLScanHip", []), ("RadixHip", []),
+                                         ("GroupByHip", ["--groups_count", "64"]),
+                                         ("GroupByLocalHip", ["--groups_count", "64", "--executors", "16"]),
+                                         ("JoinOmnisciHip", []), ("JoinHip", []), ("ProbeHip", []), ("ReduceHip", [])])
+def test_fault_injection_flips_valid(dwarf, extra, limit):
+    """DWARF_BENCH_INJECT_FAULT=1 corrupts one word of every result before it is checked: every iteration must be
+    reported invalid, by the host checks and by the device-side validators alike"""
+    import os
+    env = {**os.environ, "DWARF_BENCH_INJECT_FAULT": "1", "DWARF_BENCH_VALIDATE_MAX": limit}
+    r = _run([dwarf, "--device=hip", "--iterations", "3", "--input_size", "262144"] + extra, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("ncorrect results") == 3, r.stderr
+    env.pop("DWARF_BENCH_INJECT_FAULT")
+    r = _run([dwarf, "--device=hip", "--iterations", "3", "--input_size", "262144"] + extra, env=env)
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
+
+
+def test_probe_dwarf_over_the_bitmask_table():
+    """ProbeHip (probe/slab_probe.cpp:9-107) over the SimpleNonOwningHashTable counterpart"""
+    import os
+    r = _run(["ProbeHip", "--device=hip", "--iterations", "3", "--input_size"] + SIZES + ["1048576"],
+             env={**os.environ, "DWARF_BENCH_PROBE_TABLE": "bitmask"})
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 3 * (len(SIZES) + 1)
+
+
+def test_scan_host_time_with_transfers(tmp_path):
+    """DWARF_BENCH_TIME_TRANSFERS=1: host_time spans H2D of src + kernel + D2H of n ints (scan/scan.cpp:107-128), so
+    it exceeds the resident-data figure by at least the PCIe time of 2 x 64 MiB"""
+    import os
+
+    def host_ms(env):
+        rep = tmp_path / f"r{len(env)}.csv"
+        r = _run(["TwoPassScanHip", "--device=hip", "--iterations", "5", "--input_size", "16777216", f"--report_path={rep}"],
+                 env={**os.environ, **env})
+        assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
+        rows = list(csv.reader(rep.open()))[1:]
+        return sorted(float(x[2]) for x in rows)[len(rows) // 2], sorted(float(x[3]) for x in rows)[len(rows) // 2]
+
+    resident, k0 = host_ms({})
+    with_copies, k1 = host_ms({"DWARF_BENCH_TIME_TRANSFERS": "1"})
+    assert with_copies > resident + 1.5  # 128 MiB over PCIe gen5 x16 >= 2 ms; pageable copies take longer
+    assert k1 < 1.0 and k0 < 1.0  # kernel_time is the same small figure either way

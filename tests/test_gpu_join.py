@@ -148,3 +148,43 @@ def test_ujoin_baseline_size_properties():
     assert bool((o1[~hit] == -1).all()) and bool((o2[~hit] == -1).all())
     pos = torch.searchsorted(ak.to(torch.int64) & 0xFFFFFFFF, bk.to(torch.int64) & 0xFFFFFFFF).clamp_(max=n - 1)
     assert int(hit.sum()) == int((ak[pos] == bk).sum())
+
+
+def test_sentinel_key_is_flagged_not_joined():
+    """0xFFFFFFFF is the empty-slot marker (join/join_omnisci.cpp:52): as a build key it raises DEV_KEY_RANGE and
+    is dropped (the status word marks the result as invalid), as a probe key it finds nothing and nothing is flagged"""
+    from dwarf_bench_amd import _capi, ops
+    n = 1 << 17
+    a = ops.gen_uniform_u32(n, 5, 0, n - 1)
+    b = ops.gen_uniform_u32(n, 6, 0, n - 1)
+    b[7] = -1
+    b[n - 3] = -1
+    pos, cnt, ids = ops.hash_join(a, b)  # sentinel on the probe side only: a clean status
+    exp = po.join_counts_fast(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
+    assert int(cnt[7]) == 0 and int(cnt[n - 3]) == 0 and np.array_equal(cnt.cpu().numpy().view(np.uint32), exp.astype(np.uint32))
+    a2 = a.clone()
+    a2[11] = -1
+    plan = ops.HashJoin(n, n)
+    plan.build(a2)
+    plan.probe(b)
+    assert ops.workspace_status(plan.ws) == ops.DEV_KEY_RANGE
+    with pytest.raises(_capi.DbhipError):
+        plan.result()
+    for nn in (1000, 1 << 17):  # unique-key join: small CAS table and the partitioned path
+        ak = ops.gen_unique_sorted_u32(nn, 11)
+        ak[5] = -1
+        uj = ops.UniqueJoin(nn, nn)
+        uj.build(ak, ak)
+        assert ops.workspace_status(uj.ws) == ops.DEV_KEY_RANGE
+
+
+def test_join_answers_records():
+    """JoinOneToMany {pointer into the id buffer, size} (common/dpcpp/omnisci_hashtable.hpp:12-17)"""
+    from dwarf_bench_amd import ops
+    n = 5000
+    a = ops.gen_uniform_u32(n, 3, 1, 1000)
+    b = ops.gen_uniform_u32(n, 4, 1, 1200)
+    pos, cnt, ids = ops.hash_join(a, b)
+    ans = ops.join_answers(ids, pos, cnt).cpu().numpy()
+    assert np.array_equal(ans[:, 1], cnt.cpu().numpy().astype(np.int64))
+    assert np.array_equal(ans[:, 0], ids.data_ptr() + 4 * pos.cpu().numpy().astype(np.int64))

@@ -89,3 +89,13 @@ def test_nested_join_agrees_with_hash_join_counts():
     j.build(_dev(build))
     j.probe(_dev(probe))
     assert np.array_equal(j.result()[1].cpu().numpy().view(np.uint32)[:n], per_probe.astype(np.uint32))
+
+
+def test_reduce_unaligned_column():
+    """any 4-byte aligned column: the elements in front of the first 16-byte boundary are added one by one"""
+    from dwarf_bench_amd import ops
+    base = ops.gen_uniform_u32(300011, 8, 0, 2**32 - 1)
+    for off in (1, 2, 3):
+        src = base[off:]
+        assert int(ops.reduce_sum(src).cpu()[0]) == po.reduce_sum(src.cpu().numpy())
+    assert int(ops.reduce_sum(base[1:3]).cpu()[0]) == po.reduce_sum(base[1:3].cpu().numpy())

@@ -93,3 +93,18 @@ def test_large_input_properties_2_30():
     top = (keys.to(torch.int64) & 0xFFFFFFFF) >> 24
     c = torch.bincount(top, minlength=256)
     assert int(c.sum()) == n and float(c.max()) / float(c.min()) < 1.01
+
+
+def test_empty_input_and_unaligned_column():
+    """n == 0 leaves a clean status word in whatever workspace is passed; a column that does not start on a
+    16-byte boundary is refused with a clear message (include/dbhip.h)"""
+    from dwarf_bench_amd import ops
+    empty = torch.empty(0, dtype=torch.int32, device="cuda")
+    assert ops.radix_sort_(empty).numel() == 0
+    plan = ops.RadixSort(0)
+    plan.ws.fill_(0xAB)
+    plan.launch(empty)
+    assert ops.workspace_status(plan.ws) == 0
+    keys = ops.gen_uniform_u32(1001, 1, 0, 2**32 - 1)
+    with pytest.raises(ValueError, match="16-byte"):
+        ops.radix_sort_(keys[1:])

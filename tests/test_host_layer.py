@@ -69,7 +69,8 @@ def test_cli_list_and_exit_codes():
     assert r.returncode == 0
     names = [l.strip() for l in r.stdout.splitlines() if l.startswith("\t")]
     assert names == sorted(["DPLScanHip", "GroupByHip", "GroupByLocalHip", "HashBuildHip", "HashBuildNonBitmaskHip", "JoinHip",
-                            "JoinOmnisciHip", "NestedLoopJoinHip", "PartitionedJoinHip", "RadixHip", "ReduceHip", "TwoPassScanHip"])
+                            "JoinOmnisciHip", "NestedLoopJoinHip", "PartitionedJoinHip", "ProbeHip", "RadixHip", "ReduceHip",
+                            "TwoPassScanHip"])
     assert "DWARF_BENCH_ROOT is set to" in r.stdout
     r = subprocess.run([str(exe), "NoSuchDwarf"], capture_output=True, text=True)
     assert r.returncode == 1 and "List supported dwarfs" in r.stderr  # main.cpp:75-79

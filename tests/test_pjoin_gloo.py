@@ -19,12 +19,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_build, n_probe, key_hi, q):
+def _worker(rank, world, port, n_build, n_probe, key_hi, q, max_elems=None, lossy=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dwarf_bench_amd import pjoin
-        from tests.pjoin_testlib import OracleBackend
+        from tests.pjoin_testlib import LossyBackend, OracleBackend
         # contiguous shards of the global columns (the last rank takes the remainder: ragged shards)
         def shard(n):
             per = n // world
@@ -34,8 +34,16 @@ def _worker(rank, world, port, n_build, n_probe, key_hi, q):
         plo, phi = shard(n_probe)
         build = po.gen_uniform_u32(bhi - blo, 42, 1, key_hi, first_index=blo)
         probe = po.gen_uniform_u32(phi - plo, 43, 1, key_hi, first_index=plo)
-        res = pjoin.partitioned_join(torch.from_numpy(build.view(np.int32).copy()), torch.from_numpy(probe.view(np.int32).copy()),
-                                     blo, plo, backend=OracleBackend())
+        args = (torch.from_numpy(build.view(np.int32).copy()), torch.from_numpy(probe.view(np.int32).copy()), blo, plo)
+        if lossy:
+            try:
+                pjoin.partitioned_join(*args, backend=LossyBackend(rank))
+                q.put((rank, "no error"))
+            except pjoin.ExchangeError as e:
+                q.put((rank, str(e)))
+            dist.barrier()
+            return
+        res = pjoin.partitioned_join(*args, backend=OracleBackend(), max_message_elems=max_elems)
         u = lambda t: t.numpy().view(np.uint32).copy()
         q.put((rank, u(res.probe_row_ids), u(res.pos), u(res.cnt), u(res.build_row_ids), res.sent_rows,
                res.recv_build_rows, res.recv_probe_rows))
@@ -44,13 +52,17 @@ def _worker(rank, world, port, n_build, n_probe, key_hi, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_build,n_probe,key_hi", [(2, 600, 500, 300), (3, 1001, 777, 10000), (2, 64, 0, 10)])
-def test_partitioned_join_over_gloo(world, n_build, n_probe, key_hi):
+@pytest.mark.parametrize("world,n_build,n_probe,key_hi,max_elems", [
+    (2, 600, 500, 300, None), (3, 1001, 777, 10000, None), (2, 64, 0, 10, None),
+    # messages cut into rounds (the product's limit is 2^28 elements; forced small here): segments of ~300 rows go out
+    # in pieces of 64 / 97 (ragged last round, a different number of rounds per peer) / 1 element
+    (2, 600, 500, 300, 64), (3, 1001, 777, 10000, 97), (2, 40, 30, 10, 1)])
+def test_partitioned_join_over_gloo(world, n_build, n_probe, key_hi, max_elems):
     from tests.pjoin_testlib import check_global, dest_of
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_build, n_probe, key_hi, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_build, n_probe, key_hi, q, max_elems)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in range(world)]
@@ -77,3 +89,20 @@ def test_world_size_one_is_a_plain_join():
                                  backend=OracleBackend())
     u = lambda t: t.numpy().view(np.uint32)
     check_global([(u(res.probe_row_ids), u(res.pos), u(res.cnt), u(res.build_row_ids))], b, p)
+
+
+def test_conservation_check_raises_on_every_rank():
+    """a column whose received sum differs from the sent one (here: a backend that misreports one sum on rank 1)
+    makes partitioned_join raise ExchangeError on EVERY rank — the check is collective"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 600, 500, 300, q, None, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("did not conserve column(s) [1]" in outs[r] for r in range(world)), outs
