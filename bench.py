@@ -33,6 +33,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300-6970 GB/s is what a bare stream reaches
+RANDOM_GATHER_PEAK_G = 53.0  # G random 4..16-byte gathers/s into a table >= 64 MiB, measured with tools/ubench.hip
+LDS_ATOMIC_PEAK_G = 830.0    # G ds_add/s chip-wide, measured with tools/ubench.hip
 
 
 def _dist_env():
@@ -63,7 +65,8 @@ def _drop_max_mean(xs):
 
 
 def _traffic_for(name: str):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None."""
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None.
+    The counters need their own profiler passes (MI355X_MICROARCH.md): they are NOT measured in this run."""
     p = ROOT / "profiles" / "hbm_traffic.json"
     if not p.exists():
         return None
@@ -73,10 +76,22 @@ def _traffic_for(name: str):
         return None
 
 
+def _traffic_source():
+    """where `roofline.traffic` / `pmc_traffic_bytes` come from: file + the provenance block the profile tool wrote"""
+    p = ROOT / "profiles" / "hbm_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        src = json.loads(p.read_text()).get("_source")
+    except Exception:
+        src = None
+    return {"file": "profiles/hbm_traffic.json", "measured_in_this_run": False, "provenance": src}
+
+
 # ---------------------------------------------------------------------------------------------------
 # single-GPU dwarfs
 # ---------------------------------------------------------------------------------------------------
-def bench_scan(steps, warmup, log2n=28, filt=5):
+def bench_scan(steps, warmup, log2n=28, filt=5, cold=False):
     import torch
     from dwarf_bench_amd import ops
     n = 1 << log2n
@@ -95,7 +110,22 @@ def bench_scan(steps, warmup, log2n=28, filt=5):
     matches = plan.result().numel()
     alg_bytes = 4 * n + 4 * matches  # 4*N*(1+s)
     avg_us = sum(ev) / len(ev)
+    # cold-buffer control: the timed loop above scans the SAME 1 GiB every step; here the steps rotate over five
+    # distinct 1 GiB copies of the column (5 GiB >> the 256 MiB Infinity Cache), so no step can find its input on-die
+    cold_ms = None
+    if cold:
+        copies = [src] + [src.clone() for _ in range(4)]
+        for i in range(len(copies)):
+            plan.launch(copies[i], filt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            plan.launch(copies[i % len(copies)], filt)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - t0) * 1e3 / steps
+        del copies
     return {
+        "cold_ms_per_step": cold_ms,
         "rows": n, "ms_per_step": wall_ms, "kernel_us_avg": avg_us, "kernel_us_dropmax_mean": _drop_max_mean(ev),
         "kernel_us_min": min(ev), "mrows_per_s": n / (wall_ms * 1e3), "matches": matches,
         "algorithmic_bytes": alg_bytes, "achieved_gbs": alg_bytes / avg_us / 1e3,
@@ -145,6 +175,9 @@ def bench_groupby(steps, warmup, log2n=26, groups=1 << 16):
     alg = 8 * n + 4 * groups
     return {"rows": n, "groups": groups, "kernel_us": us, "mrows_per_s": n / us, "algorithmic_bytes": alg,
             "achieved_gbs": alg / us / 1e3, "frac_of_hbm_peak": alg / us / 1e3 / HBM_PEAK_GBS,
+            # the aggregate kernel issues one ds_add per row: it is LDS-atomic-bound before it is HBM-bound
+            "roofline_lds_atomic": {"bound": "lds_atomic", "kernel": "gb_aggregate_kernel", "achieved": n / us / 1e3,
+                                    "peak": LDS_ATOMIC_PEAK_G, "unit": "G ds_add/s", "frac": n / us / 1e3 / LDS_ATOMIC_PEAK_G},
             "workload": f"GroupBy SUM 2^{log2n} rows / {groups} groups"}
 
 
@@ -165,6 +198,10 @@ def bench_join(steps, warmup, log2n=26):
     return {"rows": 2 * n, "build_us": bu, "probe_us": pu, "kernel_us": bu + pu, "mrows_per_s": 2 * n / (bu + pu),
             "algorithmic_bytes": alg, "achieved_gbs": alg / (bu + pu) / 1e3,
             "frac_of_hbm_peak": alg / (bu + pu) / 1e3 / HBM_PEAK_GBS,
+            # what the probe's access pattern allows: one random table access per probe row; the chip serves ~53 G
+            # random 16-B gathers/s from tables >= 64 MiB (tools/ubench.hip), whatever the HBM byte rate
+            "roofline_gather": {"bound": "random_gather", "kernel": "jl_probe_kernel", "achieved": n / pu / 1e3,
+                                "peak": RANDOM_GATHER_PEAK_G, "unit": "G gathers/s", "frac": n / pu / 1e3 / RANDOM_GATHER_PEAK_G},
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 
@@ -217,6 +254,84 @@ def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
             "rows_exchanged": int(stats[1]), "exchange_conserved_in_warmup": bool(warmup > 0 and world > 1),
             "max_over_mean_rows_per_rank": float(mx[2]) * world / max(int(stats[2]), 1),
             "workload": f"radix-partitioned HashJoin 2^{log2_total} x 2^{log2_total} uint32 keys over {world} GPU(s)"}
+
+
+def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo=False):
+    """The same join on the C++ host the `PartitionedJoinHip` dwarf runs on (dwarf_bench_amd/host/pjoin_engine.cpp
+    through libdbench.so): one process per GPU, per-rank compute + exchange streams, counts by ncclAllGather, one
+    RCCL send/recv group per relation.  solo: this process alone joins the whole input on its GPU (plain local join —
+    the P = 1 point of the scaling curve); the other ranks of the job do not take part."""
+    import torch
+    from dwarf_bench_amd import pjoin_native
+    total = 1 << log2_total
+    multi = dist is not None and world > 1 and not solo
+    nid = None
+    if multi:
+        box = [pjoin_native.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        nid = box[0]
+    eng = pjoin_native.NativePartitionedJoin(total, rank if multi else 0, world if multi else 1, local, nid,
+                                             direct_single=not multi)
+
+    def sync():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(max(1, warmup)):
+        last = eng.step()
+    chk = eng.check()  # device-side checks + conservation over all ranks (collective), outside the timed region
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = eng.step()
+    sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    eng.close()
+    words = torch.tensor([chk["bad_pairs"], chk["bad_route"], chk["bad_rows"], chk["matches"], chk["sent_rows"],
+                          chk["recv_build"] + chk["recv_probe"]], dtype=torch.int64, device="cuda")
+    mx = words.clone()
+    if multi:
+        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        dist.all_reduce(words)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    w = [int(x) for x in words.cpu().tolist()]
+    n_ranks = world if multi else 1
+    return {"rows": 2 * total, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
+            "rows_exchanged": w[4], "bytes_sent_per_gpu": w[4] * 8 / n_ranks,
+            "max_over_mean_rows_per_rank": float(mx[5]) * n_ranks / max(w[5], 1),
+            "checks": {"damaged_pairs": w[0], "misrouted_keys": w[1], "wrong_probe_rows": w[2],
+                       "exchange_conserved": bool(chk["conserved"]), "all_rows_delivered": w[5] == 2 * total},
+            "phase_us_rank0_last_step": {k: round(v, 1) for k, v in (last or {}).items()},
+            "host": "C++ pjoin::Engine (libdbench.so, the PartitionedJoinHip dwarf's host): per-rank compute + exchange "
+                    "HIP streams, ncclAllGather of the count matrix, one ncclSend/ncclRecv group per relation"
+                    if multi else "C++ pjoin::Engine, one rank: plain local join (no partition, no exchange)",
+            "workload": f"radix-partitioned HashJoin 2^{log2_total} x 2^{log2_total} uint32 keys over {n_ranks} GPU(s)"}
+
+
+class _Watchdog:
+    """A multi-GPU leg that hangs (an RCCL call that never returns cannot be interrupted from Python) must not cost
+    the whole line: after `seconds` rank 0 prints what has been measured so far, with the hung leg named, and every
+    rank leaves."""
+
+    def __init__(self, seconds, rank, out):
+        import threading
+        self.rank, self.out, self.leg, self.seconds = rank, out, "start", seconds
+        self.timer = threading.Timer(seconds, self._bail)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _bail(self):
+        if self.rank == 0:
+            self.out.setdefault("pjoin", {})["error"] = f"watchdog: leg '{self.leg}' did not finish within {self.seconds} s"
+            print(json.dumps(self.out), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.timer.cancel()
 
 
 def scan_selectivity_sweep(src, plan, n):
@@ -351,7 +466,7 @@ def main():
 
     # ---- headline: scan 2^28 (BASELINE.json's metric configuration)
     barrier()
-    scan = bench_scan(args.steps, args.warmup)
+    scan = bench_scan(args.steps, args.warmup, cold=(n_gpus == 1 and not args.no_sweep))
     barrier()
     ms = scan["ms_per_step"]
     if dist is not None:
@@ -369,9 +484,17 @@ def main():
                    "parallelism": "single GPU" if n_gpus == 1 else f"{n_gpus} independent replicas (scan does not shard)"},
         "roofline": {"bound": "hbm", "achieved": scan["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": scan["achieved_gbs"] / HBM_PEAK_GBS, "traffic": _traffic_for("scan"),
+                     "traffic_source": _traffic_source(),
                      "kernel": "scan_chunk_kernel (+ scan_move_kernel in the same event bracket)",
-                     "kernel_us_avg": scan["kernel_us_avg"], "algorithmic_bytes": scan["algorithmic_bytes"]},
+                     "kernel_us_avg": scan["kernel_us_avg"], "algorithmic_bytes": scan["algorithmic_bytes"],
+                     "kernel_us_avg_note": "HIP events around every call in a second loop of `steps` calls (event "
+                                           "records between the calls); ms_per_step is the wall clock of the "
+                                           "back-to-back loop — two loops, so the two figures differ by ~1 %"},
     }
+    if scan["cold_ms_per_step"] is not None:
+        # the same scan with NO step finding its input in the Infinity Cache (five 1 GiB copies in rotation)
+        out["value_cold"] = n_gpus * scan["rows"] / (scan["cold_ms_per_step"] * 1e3)
+        out["cold_over_warm_time"] = scan["cold_ms_per_step"] / scan["ms_per_step"]
 
     if rank == 0:
         # one-off result check against the oracle on a bounded prefix (never inside the timed region)
@@ -406,8 +529,11 @@ def main():
             dwarfs["join"] = bench_join(max(3, k // 2), 2)
             torch.cuda.empty_cache()
             if not args.no_pjoin:
-                pj = bench_pjoin(2, 1, 30, None)  # the single-GPU point of the partitioned join's scaling curve
-                dwarfs["pjoin_p1"] = {k2: v for k2, v in pj.items()}
+                # the single-GPU point of the partitioned join's scaling curve: C++ host (the dwarf's engine), and the
+                # torch.distributed host beside it
+                dwarfs["pjoin_p1"] = bench_pjoin_native(3, 1, 30, None, 0, 1, local, solo=True)
+                torch.cuda.empty_cache()
+                dwarfs["pjoin_p1_torch_host"] = bench_pjoin(2, 1, 30, None)
         if not args.no_cpu:
             want = [w for w in ("sort", "groupby", "join") if args.dwarf in ("all", w)]
             for name, base in cpu_baselines_dwarfs(want).items():
@@ -421,31 +547,60 @@ def main():
     if n_gpus > 1:
         # ---- the one part of the hot path that shards (BASELINE north_star): the hash join, radix-partitioned
         # across the ranks with an RCCL all-to-all bucket exchange.  STRONG scaling: 2^30 x 2^30 in total whatever N
-        # is.  Its single-GPU reference point is measured in this same run, on rank 0's GPU, while the other ranks
-        # wait — so the speed-up is self-contained in this line.
+        # is.  Two hosts drive the same device kernels and are both reported: the C++ engine of the PartitionedJoinHip
+        # dwarf (`pjoin`, the headline of this section) and the torch.distributed one (`pjoin.torch_distributed_host`).
+        # Each one's single-GPU reference point is measured in this same run, on rank 0's GPU, while the other ranks
+        # wait — so the speed-ups are self-contained in this line.
         torch.cuda.empty_cache()
         pj_steps, pj_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
         pj_log2 = int(os.environ.get("DBENCH_PJOIN_LOG2", "30"))
-        pj = bench_pjoin(pj_steps, pj_warm, pj_log2, dist)
-        torch.cuda.empty_cache()
-        solo = dist.new_group(ranks=[0])  # collective call; only rank 0 uses it: its join below is purely local
-        p1 = bench_pjoin(2, 1, pj_log2, None, group=solo) if rank == 0 else None
-        barrier()
+        dog = _Watchdog(int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")), rank, out)
+        section = {"metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
+                   "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm}
         if rank == 0:
-            out["pjoin"] = {
-                "metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
-                "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm,
-                "parallelism": f"hash-partitioned over {n_gpus} ranks, all_to_all bucket exchange (RCCL over xGMI) "
-                               "overlapped with partition/build, local LDS-partitioned join per rank",
-                **{k: v for k, v in pj.items()},
-                "bytes_sent_per_gpu": pj["rows_exchanged"] * 8 / n_gpus,
-                "single_gpu_ms_per_step": p1["ms_per_step"], "single_gpu_mrows_per_s": p1["mrows_per_s"],
-                "speedup_vs_1gpu": p1["ms_per_step"] / pj["ms_per_step"],
-                "matches_equal_single_gpu": pj["matches"] == p1["matches"],
-            }
+            out["pjoin"] = section
+        try:
+            dog.leg = "torch.distributed host, all ranks"
+            pj = bench_pjoin(pj_steps, pj_warm, pj_log2, dist)
+            torch.cuda.empty_cache()
+            dog.leg = "torch.distributed host, one GPU"
+            solo = dist.new_group(ranks=[0])  # collective call; only rank 0 uses it: its join below is purely local
+            p1 = bench_pjoin(2, 1, pj_log2, None, group=solo) if rank == 0 else None
+            barrier()
+            torch.cuda.empty_cache()
+            if rank == 0:
+                section["torch_distributed_host"] = {
+                    "parallelism": f"hash-partitioned over {n_gpus} ranks, all_to_all bucket exchange (RCCL over xGMI) "
+                                   "overlapped with partition/build, local LDS-partitioned join per rank",
+                    **pj, "bytes_sent_per_gpu": pj["rows_exchanged"] * 8 / n_gpus,
+                    "single_gpu_ms_per_step": p1["ms_per_step"], "single_gpu_mrows_per_s": p1["mrows_per_s"],
+                    "speedup_vs_1gpu": p1["ms_per_step"] / pj["ms_per_step"],
+                    "matches_equal_single_gpu": pj["matches"] == p1["matches"]}
+        except Exception as e:  # keep the line: the other host is still to come
+            if rank == 0:
+                section["torch_distributed_host"] = {"error": repr(e)}
+        if os.environ.get("DBENCH_BACKEND", "nccl") == "nccl":  # the C++ engine talks RCCL: needs one GPU per rank
+            try:
+                dog.leg = "C++ engine, all ranks"
+                cx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local)
+                torch.cuda.empty_cache()
+                dog.leg = "C++ engine, one GPU"
+                c1 = bench_pjoin_native(2, 1, pj_log2, dist, rank, world, local, solo=True) if rank == 0 else None
+                barrier()
+                if rank == 0:
+                    section.update(cx)
+                    section.update({"single_gpu_ms_per_step": c1["ms_per_step"], "single_gpu_mrows_per_s": c1["mrows_per_s"],
+                                    "speedup_vs_1gpu": c1["ms_per_step"] / cx["ms_per_step"],
+                                    "matches_equal_single_gpu": cx["matches"] == c1["matches"]})
+            except Exception as e:
+                if rank == 0:
+                    section["error"] = repr(e)
+        elif rank == 0:
+            section["note"] = "rehearsal backend: ranks share GPUs, the C++ RCCL engine needs one GPU per rank and is skipped"
+        dog.cancel()
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "dbhip_pjoin_partition_workspace_bytes": (_sz, [_sz, _u32]),
     "dbhip_pjoin_partition_u32": (_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dbhip_gather_u32": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "dbhip_check_pjoin_route_u32": (_int, [_vp, _sz, _u32, _u32, _vp, _vp]),
     "dbhip_reduce_sum_i32": (_int, [_vp, _sz, _vp, _vp]),
     "dbhip_nested_join_u32": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "dbhip_exclusive_scan_u32_workspace_bytes": (_sz, [_sz]),

@@ -60,6 +60,8 @@ size_t jl_partition_workspace_bytes(unsigned parts);
 int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, unsigned parts, unsigned *out_keys,
                  unsigned *out_rids, unsigned long long *out_counts, void *workspace, hipStream_t s,
                  const DeviceInfo &dev);
+int jl_route_check(const unsigned *keys, size_t n, unsigned parts, unsigned rank, unsigned long long *result,
+                   hipStream_t s, const DeviceInfo &dev);
 int ujoin_lds_build(const unsigned *build_keys, const unsigned *build_vals, size_t n, void *workspace, hipStream_t s,
                     const DeviceInfo &dev);
 int ujoin_lds_probe(const unsigned *probe_keys, const unsigned *probe_vals, size_t n_probe, const void *workspace,

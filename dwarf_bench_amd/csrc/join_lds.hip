@@ -768,6 +768,32 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
   return launch_status();
 }
 
+// how many of `keys` do NOT belong to bucket `rank` of `parts` under the rank hash (validator of the exchange's routing)
+__global__ __launch_bounds__(kJlThreads) void jl_route_check_kernel(const unsigned *__restrict__ keys, size_t n,
+                                                                    unsigned parts, unsigned rank,
+                                                                    unsigned long long *result) {
+  __shared__ unsigned s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  unsigned bad = 0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
+    bad += jl_rank_of(keys[i], parts) != rank;
+  bad = wave_reduce_add(bad);
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1 && bad) atomicAdd(&s_bad, bad);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_bad) atomicAdd(result, static_cast<unsigned long long>(s_bad));
+}
+
+int jl_route_check(const unsigned *keys, size_t n, unsigned parts, unsigned rank, unsigned long long *result,
+                   hipStream_t s, const DeviceInfo &dev) {
+  const hipError_t e = fill_async(result, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (n == 0) return DBHIP_OK;
+  hipLaunchKernelGGL(jl_route_check_kernel, dim3(jl_grid(n, dev, 8)), dim3(kJlThreads), 0, s, keys, n, parts, rank, result);
+  return launch_status();
+}
+
 // ---- stand-alone level-0 partition (multi-GPU join: bucket = destination rank) ------------------------
 // 2^27 rows into 8 buckets: histogram 158 us + scatter 566 us (into 2 buckets: 285 + 700 us — the LDS atomics of a
 // wave land on very few addresses).  Counting and ranking by ballot in wave-uniform registers instead (16 unrolled

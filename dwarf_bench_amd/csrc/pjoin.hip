@@ -77,6 +77,14 @@ extern "C" int dbhip_pjoin_partition_u32(const uint32_t *keys, size_t n, uint64_
                       reinterpret_cast<unsigned long long *>(out_counts), workspace, as_stream(stream), dev);
 }
 
+extern "C" int dbhip_check_pjoin_route_u32(const uint32_t *keys, size_t n, uint32_t parts, uint32_t rank, uint64_t *result,
+                                           dbhip_stream_t stream) {
+  if (!result || (n && !keys) || parts < 1 || parts > kPjMaxParts || rank >= parts) return DBHIP_EINVAL;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  return jl_route_check(keys, n, parts, rank, reinterpret_cast<unsigned long long *>(result), as_stream(stream), dev);
+}
+
 extern "C" int dbhip_gather_u32(const uint32_t *table, const uint32_t *idx, size_t n, uint32_t *out,
                                 dbhip_stream_t stream) {
   if (n == 0) return DBHIP_OK;

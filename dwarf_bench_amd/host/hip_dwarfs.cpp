@@ -888,245 +888,49 @@ void NestedLoopJoinHip::run(const RunOptions &opts) {
 void NestedLoopJoinHip::init(const RunOptions &opts) { common_init(*this, opts); }
 
 // =====================================================================================================
-// PartitionedJoinHip — the radix-partitioned hash join of SURVEY 8(e) behind the Dwarf hook, one process driving
-// `--gpus P` ranks (no reference counterpart; JoinOmnisci semantics, join/join_omnisci.cpp:49-118).
-// `buf_size` rows per relation IN TOTAL; rank r owns the contiguous shard [r*n/P, (r+1)*n/P) of both key columns,
-// generated in place on its GPU.  Per iteration, phase by phase (every phase ends with a sync of all ranks, like the
-// reference's .wait() after every submit):
-//   partition  dbhip_pjoin_partition_u32 on both shards -> bucket-major (key, global row id) pairs + counts
-//   exchange   bucket d of every rank goes to rank d.  Ranks on distinct GPUs: ONE RCCL group of ncclSend/ncclRecv
-//              for all four columns (every GPU talks to every peer at once: one xGMI link per pair, no ring).
-//              More ranks than GPUs (rehearsal on one GPU, DWARF_BENCH_PJOIN_EXCHANGE=copy forces it): the same
-//              transfers as hipMemcpyPeerAsync pushes.
-//   build      dbhip_join_build_pairs_u32 on the received pairs: the id buffer holds GLOBAL build row ids
-//   probe      dbhip_join_probe_u32; results stay sharded by key hash: (probe global row id, pos, cnt) + ids.
-// The python path (dwarf_bench_amd/pjoin.py, one process per GPU, torch.distributed) pipelines these phases; here
-// they are timed separately.  HashJoinResult: build_time = partition + exchange + build, probe_time = probe.
-#include <rccl/rccl.h>
-
-namespace {
-
-void nccl_ok(ncclResult_t r, const char *what) {
-  if (r != ncclSuccess) fail(std::string(what) + ": " + ncclGetErrorString(r));
-}
-
-struct DevMem {  // hipMalloc on a given device
-  int dev = 0;
-  void *p = nullptr;
-  DevMem() = default;
-  DevMem(int device, size_t bytes) : dev(device) {
-    hip_ok(hipSetDevice(dev), "hipSetDevice");
-    hip_ok(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc");
-  }
-  DevMem(DevMem &&o) noexcept : dev(o.dev), p(o.p) { o.p = nullptr; }
-  DevMem &operator=(DevMem &&o) noexcept {
-    release();
-    dev = o.dev;
-    p = o.p;
-    o.p = nullptr;
-    return *this;
-  }
-  DevMem(const DevMem &) = delete;
-  DevMem &operator=(const DevMem &) = delete;
-  ~DevMem() { release(); }
-  void release() {
-    if (p) {
-      (void)hipSetDevice(dev);
-      (void)hipFree(p);
-      p = nullptr;
-    }
-  }
-  template <class T>
-  T *as() const { return static_cast<T *>(p); }
-};
-
-struct PjRank {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  size_t lo = 0, n_local = 0;
-  DevMem build, probe, pk_r, pr_r, pk_s, pr_s, cnt_dev, part_ws, chk;
-  size_t part_ws_bytes = 0;
-  std::vector<uint64_t> send_r, send_s;  // rows for every destination rank
-  size_t recv_r = 0, recv_s = 0;
-  DevMem rk, rr, sk, sr, join_ws, ids, pos, cnt;
-  size_t join_ws_bytes = 0;
-};
-
-template <class T>
-std::vector<T> d2h(const void *src, size_t count, int dev) {
-  std::vector<T> h(count);
-  hip_ok(hipSetDevice(dev), "hipSetDevice");
-  if (count) hip_ok(hipMemcpy(h.data(), src, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
-  return h;
-}
-
-}  // namespace
+// PartitionedJoinHip — the radix-partitioned hash join of SURVEY 8(e) behind the Dwarf hook: one process driving
+// `--gpus P` ranks through pjoin::Engine (pjoin_engine.hpp: per-rank compute and exchange streams, counts by
+// ncclAllGather, exchange of R overlapping partition S, exchange of S overlapping build R).  No reference
+// counterpart; JoinOmnisci semantics (join/join_omnisci.cpp:49-118).  `buf_size` rows per relation IN TOTAL; rank r
+// owns the contiguous shard [r*n/P, (r+1)*n/P) of both key columns, generated in place on its GPU.
+// Ranks on distinct GPUs exchange through ONE RCCL group of ncclSend/ncclRecv per relation; more ranks than GPUs
+// (rehearsal on one GPU; DWARF_BENCH_PJOIN_EXCHANGE=copy forces it) share devices and push with hipMemcpyPeerAsync.
+// DWARF_BENCH_PJOIN_DIRECT=1 with --gpus 1: the plain local join (the P = 1 point of a scaling curve).
+// HashJoinResult: build_time = start -> every rank's build done, probe_time = the rest; the phase lines printed per
+// iteration are device-event spans (max over ranks) and overlap by design.
+// Checks, every iteration and at every size, on the device: the exchange conserves the four columns (wrap-around
+// sums sent == received), every received pair is what the generator produced for its row id, every received key
+// hashes to the receiving rank, every probe row's count equals the key's multiplicity among the rank's build keys
+// and its ids carry the key.  Up to DWARF_BENCH_VALIDATE_MAX rows additionally on the host against per-key counts
+// of the whole build column (all rows of a key must have met on ONE rank).
+#include "pjoin_engine.hpp"
 
 PartitionedJoinHip::PartitionedJoinHip() : Dwarf("PartitionedJoinHip") {}
 void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
   const RunOptions &opts = meter.opts();
   banner("PartitionedJoinHip");
-  const unsigned P = static_cast<unsigned>(opts.devices ? opts.devices : 1);
-  if (P > 256) fail("PartitionedJoinHip: at most 256 ranks");
-  if (n > 0xFFFFFFFFull) fail("PartitionedJoinHip: global row ids must fit 32 bits");
+  pjoin::Options po;
+  po.world = static_cast<unsigned>(opts.devices ? opts.devices : 1);
+  const char *force = std::getenv("DWARF_BENCH_PJOIN_EXCHANGE");
+  po.force_copy = force && std::string(force) == "copy";
+  po.direct_single = env_flag("DWARF_BENCH_PJOIN_DIRECT");
   int ndev = 0;
   hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
-  const char *force = std::getenv("DWARF_BENCH_PJOIN_EXCHANGE");
-  const bool use_rccl = static_cast<int>(P) <= ndev && !(force && std::string(force) == "copy");
+  pjoin::Engine engine(n, po);
+  const unsigned P = engine.world();
   std::cout << "PartitionedJoinHip: " << P << " rank(s) on " << std::min<int>(P, ndev) << " GPU(s), exchange by "
-            << (use_rccl ? "RCCL send/recv group" : "hipMemcpyPeerAsync") << "\n";
-  int home = 0;
-  hip_ok(hipGetDevice(&home), "hipGetDevice");
+            << (engine.uses_rccl() ? "RCCL send/recv group"
+                                   : (po.direct_single && P == 1 ? "nothing (direct local join)" : "hipMemcpyPeerAsync"))
+            << "\n";
+  engine.plan();
 
-  std::vector<PjRank> ranks(P);
-  const uint32_t key_hi = static_cast<uint32_t>(n ? n - 1 : 0);  // keys uniform in [0, n): SURVEY 8(d) join regime
-  for (unsigned r = 0; r < P; ++r) {
-    PjRank &k = ranks[r];
-    k.device = static_cast<int>(r) % ndev;
-    hip_ok(hipSetDevice(k.device), "hipSetDevice");
-    hip_ok(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking), "hipStreamCreate");
-    const size_t per = n / P;
-    k.lo = r * per;
-    k.n_local = (r == P - 1) ? n - k.lo : per;
-    const size_t col = k.n_local * sizeof(uint32_t);
-    k.build = DevMem(k.device, col);
-    k.probe = DevMem(k.device, col);
-    k.pk_r = DevMem(k.device, col);
-    k.pr_r = DevMem(k.device, col);
-    k.pk_s = DevMem(k.device, col);
-    k.pr_s = DevMem(k.device, col);
-    k.cnt_dev = DevMem(k.device, 2 * P * sizeof(uint64_t));
-    k.chk = DevMem(k.device, 8 * sizeof(int32_t));
-    k.part_ws_bytes = dbhip_pjoin_partition_workspace_bytes(k.n_local, P);
-    k.part_ws = DevMem(k.device, k.part_ws_bytes);
-    db_ok(dbhip_gen_uniform_u32(k.build.as<uint32_t>(), k.n_local, 42, k.lo, 0, key_hi, k.stream), "gen build");
-    db_ok(dbhip_gen_uniform_u32(k.probe.as<uint32_t>(), k.n_local, 43, k.lo, 0, key_hi, k.stream), "gen probe");
-  }
-  auto sync_all = [&] {
-    for (PjRank &k : ranks) {
-      hip_ok(hipSetDevice(k.device), "hipSetDevice");
-      hip_ok(hipStreamSynchronize(k.stream), "hipStreamSynchronize");
-    }
-  };
-  auto partition = [&] {
-    for (PjRank &k : ranks) {
-      hip_ok(hipSetDevice(k.device), "hipSetDevice");
-      uint64_t *c = k.cnt_dev.as<uint64_t>();
-      db_ok(dbhip_pjoin_partition_u32(k.build.as<uint32_t>(), k.n_local, k.lo, P, k.pk_r.as<uint32_t>(),
-                                      k.pr_r.as<uint32_t>(), c, k.part_ws.p, k.part_ws_bytes, k.stream),
-            "dbhip_pjoin_partition_u32");
-      db_ok(dbhip_pjoin_partition_u32(k.probe.as<uint32_t>(), k.n_local, k.lo, P, k.pk_s.as<uint32_t>(),
-                                      k.pr_s.as<uint32_t>(), c + P, k.part_ws.p, k.part_ws_bytes, k.stream),
-            "dbhip_pjoin_partition_u32");
-    }
-    sync_all();
-    for (PjRank &k : ranks) {  // the P x P count matrix, row = sender (an all-gather in a multi-process setting)
-      const auto c = d2h<uint64_t>(k.cnt_dev.p, 2 * P, k.device);
-      k.send_r.assign(c.begin(), c.begin() + P);
-      k.send_s.assign(c.begin() + P, c.end());
-    }
-    for (unsigned r = 0; r < P; ++r) {
-      ranks[r].recv_r = ranks[r].recv_s = 0;
-      for (unsigned q = 0; q < P; ++q) {
-        ranks[r].recv_r += ranks[q].send_r[r];
-        ranks[r].recv_s += ranks[q].send_s[r];
-      }
-    }
-  };
-
-  // planning pass (untimed): learn the receive sizes, allocate receive buffers, tables and outputs once
-  partition();
-  for (PjRank &k : ranks) {
-    k.rk = DevMem(k.device, k.recv_r * 4);
-    k.rr = DevMem(k.device, k.recv_r * 4);
-    k.sk = DevMem(k.device, k.recv_s * 4);
-    k.sr = DevMem(k.device, k.recv_s * 4);
-    k.join_ws_bytes = dbhip_join_workspace_bytes(k.recv_r);
-    k.join_ws = DevMem(k.device, k.join_ws_bytes);
-    k.ids = DevMem(k.device, k.recv_r * 4);
-    k.pos = DevMem(k.device, k.recv_s * 4);
-    k.cnt = DevMem(k.device, k.recv_s * 4);
-  }
-  std::vector<ncclComm_t> comms;
-  if (use_rccl) {
-    std::vector<int> devs(P);
-    for (unsigned r = 0; r < P; ++r) devs[r] = ranks[r].device;
-    comms.resize(P);
-    nccl_ok(ncclCommInitAll(comms.data(), static_cast<int>(P), devs.data()), "ncclCommInitAll");
-  } else {
-    for (PjRank &a : ranks)
-      for (PjRank &b : ranks)
-        if (a.device != b.device) {
-          hip_ok(hipSetDevice(a.device), "hipSetDevice");
-          const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
-          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_ok(e, "hipDeviceEnablePeerAccess");
-          (void)hipGetLastError();
-        }
-  }
-  auto exchange = [&] {
-    // offsets: sender side = prefix over destinations, receiver side = prefix over senders
-    std::vector<std::vector<uint64_t>> soff_r(P, std::vector<uint64_t>(P + 1, 0)), soff_s = soff_r, roff_r = soff_r,
-                                       roff_s = soff_r;
-    for (unsigned r = 0; r < P; ++r)
-      for (unsigned q = 0; q < P; ++q) {
-        soff_r[r][q + 1] = soff_r[r][q] + ranks[r].send_r[q];
-        soff_s[r][q + 1] = soff_s[r][q] + ranks[r].send_s[q];
-        roff_r[r][q + 1] = roff_r[r][q] + ranks[q].send_r[r];
-        roff_s[r][q + 1] = roff_s[r][q] + ranks[q].send_s[r];
-      }
-    if (use_rccl) nccl_ok(ncclGroupStart(), "ncclGroupStart");
-    for (unsigned r = 0; r < P; ++r) {
-      PjRank &me = ranks[r];
-      hip_ok(hipSetDevice(me.device), "hipSetDevice");
-      for (unsigned q = 0; q < P; ++q) {
-        PjRank &peer = ranks[q];
-        struct Col {
-          const uint32_t *src;
-          uint32_t *my_recv, *peer_recv;
-          uint64_t send_off, send_cnt, recv_off, recv_cnt, peer_recv_off;
-        };
-        const Col cols[4] = {
-            {me.pk_r.as<uint32_t>(), me.rk.as<uint32_t>(), peer.rk.as<uint32_t>(), soff_r[r][q], me.send_r[q], roff_r[r][q],
-             peer.send_r[r], roff_r[q][r]},
-            {me.pr_r.as<uint32_t>(), me.rr.as<uint32_t>(), peer.rr.as<uint32_t>(), soff_r[r][q], me.send_r[q], roff_r[r][q],
-             peer.send_r[r], roff_r[q][r]},
-            {me.pk_s.as<uint32_t>(), me.sk.as<uint32_t>(), peer.sk.as<uint32_t>(), soff_s[r][q], me.send_s[q], roff_s[r][q],
-             peer.send_s[r], roff_s[q][r]},
-            {me.pr_s.as<uint32_t>(), me.sr.as<uint32_t>(), peer.sr.as<uint32_t>(), soff_s[r][q], me.send_s[q], roff_s[r][q],
-             peer.send_s[r], roff_s[q][r]},
-        };
-        for (const Col &c : cols) {
-          if (use_rccl) {
-            // pieces of at most 2^28 elements (1 GiB): one ncclSend/ncclRecv of 2^29 uint32 (2 GiB) was measured to
-            // deliver garbage without any error (RCCL 2.27.7); both sides cut their segment the same way, so the
-            // k-th send to a peer still meets the k-th receive from it
-            constexpr uint64_t kPiece = 1ull << 28;
-            for (uint64_t o = 0; o < c.send_cnt; o += kPiece)
-              nccl_ok(ncclSend(c.src + c.send_off + o, std::min(kPiece, c.send_cnt - o), ncclUint32, static_cast<int>(q),
-                               comms[r], me.stream), "ncclSend");
-            for (uint64_t o = 0; o < c.recv_cnt; o += kPiece)
-              nccl_ok(ncclRecv(c.my_recv + c.recv_off + o, std::min(kPiece, c.recv_cnt - o), ncclUint32,
-                               static_cast<int>(q), comms[r], me.stream), "ncclRecv");
-          } else if (c.send_cnt) {
-            hip_ok(hipMemcpyPeerAsync(c.peer_recv + c.peer_recv_off, peer.device, c.src + c.send_off, me.device,
-                                      c.send_cnt * sizeof(uint32_t), me.stream),
-                   "hipMemcpyPeerAsync");
-          }
-        }
-      }
-    }
-    if (use_rccl) nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-    sync_all();
-  };
-
-  // host copy of the global columns for validation
-  const bool validate = n <= validate_limit();
+  // host copy of the global columns for the host-side check
+  const bool host_check = n <= validate_limit();
   std::vector<uint32_t> build_all, probe_all;
   std::unordered_map<uint32_t, uint32_t> key_count;
-  if (validate) {
-    sync_all();
-    for (PjRank &k : ranks) {
-      const auto b = d2h<uint32_t>(k.build.p, k.n_local, k.device), p = d2h<uint32_t>(k.probe.p, k.n_local, k.device);
+  if (host_check) {
+    for (unsigned r = 0; r < engine.local_ranks(); ++r) {
+      const auto b = engine.download_column(r, true), p = engine.download_column(r, false);
       build_all.insert(build_all.end(), b.begin(), b.end());
       probe_all.insert(probe_all.end(), p.begin(), p.end());
     }
@@ -1135,98 +939,57 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
 
   for (size_t it = 0; it < opts.iterations; ++it) {
     auto result = std::make_unique<HashJoinResult>();
-    sync_all();
-    const auto t0 = clk::now();
-    partition();
-    const auto t1 = clk::now();
-    exchange();
-    const auto t2 = clk::now();
-    for (PjRank &k : ranks) {
-      hip_ok(hipSetDevice(k.device), "hipSetDevice");
-      db_ok(dbhip_join_build_pairs_u32(k.rk.as<uint32_t>(), k.rr.as<uint32_t>(), k.recv_r, k.ids.as<uint32_t>(), k.join_ws.p,
-                                       k.join_ws_bytes, k.stream),
-            "dbhip_join_build_pairs_u32");
+    const pjoin::StepTimes t = engine.step();
+    result->host_time = Duration(t.total);
+    result->build_time = Duration(t.until_build_done);
+    result->probe_time = Duration(t.total - t.until_build_done);
+    result->kernel_time = Duration(t.total);  // no single device timeline spans the ranks
+    std::cout << "Partition time: " << t.partition << " us\nExchange time: " << t.exchange << " us\nLocal build time: "
+              << t.build << " us\nLocal probe time: " << t.probe << " us\n";
+    if (inject_fault() && n) engine.corrupt_one_count();
+    const pjoin::CheckReport rep = engine.check();
+    bool ok = true;
+    if (!engine.conserved(rep)) {
+      std::cerr << "Incorrect results (the exchange did not conserve its columns)" << std::endl;
+      ok = false;
     }
-    sync_all();
-    const auto t3 = clk::now();
-    for (PjRank &k : ranks) {
-      hip_ok(hipSetDevice(k.device), "hipSetDevice");
-      db_ok(dbhip_join_probe_u32(k.sk.as<uint32_t>(), k.recv_s, k.join_ws.p, k.recv_r, k.pos.as<uint32_t>(),
-                                 k.cnt.as<uint32_t>(), k.stream),
-            "dbhip_join_probe_u32");
+    if (rep.bad_pairs || rep.bad_route || rep.bad_rows || rep.recv_build != n || rep.recv_probe != n) {
+      std::cerr << "Incorrect results (device checks: " << rep.bad_pairs << " damaged pairs, " << rep.bad_route
+                << " misrouted keys, " << rep.bad_rows << " wrong probe rows, " << rep.recv_build << " + " << rep.recv_probe
+                << " rows delivered)" << std::endl;
+      ok = false;
     }
-    sync_all();
-    const auto t4 = clk::now();
-    result->host_time = t4 - t0;
-    result->build_time = t3 - t0;
-    result->probe_time = t4 - t3;
-    result->kernel_time = t4 - t0;  // phases are host-timed between syncs; no single device timeline spans the ranks
-    std::cout << "Partition time: " << Duration(t1 - t0).count() << " us\nExchange time: " << Duration(t2 - t1).count()
-              << " us\nLocal build time: " << Duration(t3 - t2).count() << " us\n";
-    for (PjRank &k : ranks) {
-      hip_ok(hipSetDevice(k.device), "hipSetDevice");
-      check_status(k.join_ws.p, "PartitionedJoinHip");
-      check_status(k.part_ws.p, "PartitionedJoinHip (partition)");
-    }
-    {
-      // always on, at every size: the exchange must conserve the four columns — wrap-around sums of everything sent
-      // equal the sums of everything received (device-side reduce, ~0.2 ms per GiB)
-      int32_t sent[4] = {0, 0, 0, 0}, got[4] = {0, 0, 0, 0};
-      for (PjRank &k : ranks) {
-        hip_ok(hipSetDevice(k.device), "hipSetDevice");
-        int32_t *scratch = k.chk.as<int32_t>();
-        const void *cols[8] = {k.pk_r.p, k.pr_r.p, k.pk_s.p, k.pr_s.p, k.rk.p, k.rr.p, k.sk.p, k.sr.p};
-        const size_t lens[8] = {k.n_local, k.n_local, k.n_local, k.n_local, k.recv_r, k.recv_r, k.recv_s, k.recv_s};
-        for (int c = 0; c < 8; ++c)
-          db_ok(dbhip_reduce_sum_i32(static_cast<const int32_t *>(cols[c]), lens[c], scratch + c, k.stream),
-                "dbhip_reduce_sum_i32");
-        hip_ok(hipStreamSynchronize(k.stream), "hipStreamSynchronize");
-        const auto h = d2h<int32_t>(scratch, 8, k.device);
-        for (int c = 0; c < 4; ++c) {
-          sent[c] = static_cast<int32_t>(static_cast<uint32_t>(sent[c]) + static_cast<uint32_t>(h[c]));
-          got[c] = static_cast<int32_t>(static_cast<uint32_t>(got[c]) + static_cast<uint32_t>(h[4 + c]));
-        }
-      }
-      for (int c = 0; c < 4; ++c)
-        if (sent[c] != got[c]) {
-          std::cerr << "Incorrect results (exchange did not conserve column " << c << ")" << std::endl;
-          result->valid = false;
-        }
-    }
-    if (validate) {
-      bool ok = true;
+    if (host_check && ok) {
       std::vector<char> seen(n, 0);
       size_t delivered = 0;
-      for (PjRank &k : ranks) {
-        const auto rid = d2h<uint32_t>(k.sr.p, k.recv_s, k.device), key = d2h<uint32_t>(k.sk.p, k.recv_s, k.device),
-                   hpos = d2h<uint32_t>(k.pos.p, k.recv_s, k.device), hcnt = d2h<uint32_t>(k.cnt.p, k.recv_s, k.device),
-                   hids = d2h<uint32_t>(k.ids.p, k.recv_r, k.device);
-        for (size_t i = 0; i < k.recv_s && ok; ++i) {
-          ok = rid[i] < n && !seen[rid[i]] && probe_all[rid[i]] == key[i];  // every probe row arrives once, intact
+      uint64_t matches = 0;
+      for (unsigned r = 0; r < engine.local_ranks() && ok; ++r) {
+        const pjoin::Engine::HostShard h = engine.download(r);
+        for (size_t i = 0; i < h.probe_keys.size() && ok; ++i) {
+          const uint32_t rid = h.probe_row_ids[i], key = h.probe_keys[i];
+          ok = rid < n && !seen[rid] && probe_all[rid] == key;  // every probe row arrives once, intact
           if (!ok) break;
-          seen[rid[i]] = 1;
+          seen[rid] = 1;
           ++delivered;
-          const auto f = key_count.find(key[i]);
+          const auto f = key_count.find(key);
           const uint32_t want = f == key_count.end() ? 0u : f->second;
-          ok = hcnt[i] == want;  // all build rows with this key were routed to the same rank
-          for (uint32_t j = 0; ok && j < hcnt[i]; j += (hcnt[i] > 64 ? hcnt[i] / 64 : 1))
-            ok = hpos[i] + j < k.recv_r && hids[hpos[i] + j] < n && build_all[hids[hpos[i] + j]] == key[i];
+          ok = h.cnt[i] == want && static_cast<size_t>(h.pos[i]) + h.cnt[i] <= h.ids.size();  // all rows of the key met here
+          matches += h.cnt[i];
+          const uint32_t stepj = h.cnt[i] > 64 ? h.cnt[i] / 64 : 1;
+          for (uint32_t j = 0; ok && j < h.cnt[i]; j += stepj) {
+            const uint32_t id = h.ids[h.pos[i] + j];
+            ok = id < n && build_all[id] == key;
+          }
         }
       }
-      if (!ok || delivered != n) {
+      if (!ok || delivered != n || matches != rep.matches) {
         std::cerr << "Incorrect results" << std::endl;
-        result->valid = false;
+        ok = false;
       }
     }
+    if (!ok) result->valid = false;
     meter.add_result(size_param(n), std::move(result));
   }
-  for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
-  for (PjRank &k : ranks) {
-    (void)hipSetDevice(k.device);
-    (void)hipStreamDestroy(k.stream);
-  }
-  ranks.clear();
-  hip_ok(hipSetDevice(home), "hipSetDevice");
 }
 void PartitionedJoinHip::run(const RunOptions &opts) {
   for (auto size : opts.input_size) _run(size, meter());

@@ -1,0 +1,669 @@
+// pjoin_engine.cpp — see pjoin_engine.hpp.  Device work goes through the C ABI of include/dbhip.h only.
+#include "pjoin_engine.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+#include "../../include/dbhip.h"
+#include "bench.hpp"
+
+namespace pjoin {
+namespace {
+
+using clk = std::chrono::steady_clock;
+
+[[noreturn]] void fail(const std::string &what) { throw DwarfBench::DwarfBenchException(what); }
+void hip_ok(hipError_t e, const char *what) {
+  if (e != hipSuccess) fail(std::string(what) + ": " + hipGetErrorString(e));
+}
+void db_ok(int rc, const char *what) {
+  if (rc != 0) fail(std::string(what) + " failed with status " + std::to_string(rc));
+}
+void nccl_ok(ncclResult_t r, const char *what) {
+  if (r != ncclSuccess) fail(std::string(what) + ": " + ncclGetErrorString(r));
+}
+
+// One ncclSend/ncclRecv of 2^29 uint32 (2 GiB) completed without an error and delivered garbage (RCCL 2.27.7, caught
+// by the conservation check); pieces of 2^28 elements (1 GiB) have carried every run since.  Both sides cut a segment
+// the same way, so the k-th piece sent to a peer meets the k-th piece received from it.
+constexpr uint64_t kPiece = 1ull << 28;
+
+struct DevMem {  // hipMalloc on a given device; grows, never shrinks
+  int dev = 0;
+  void *p = nullptr;
+  size_t bytes = 0;
+  void reserve(int device, size_t want) {
+    if (want <= bytes && p) return;
+    release();
+    dev = device;
+    hip_ok(hipSetDevice(dev), "hipSetDevice");
+    hip_ok(hipMalloc(&p, std::max<size_t>(want, 256)), "hipMalloc");
+    bytes = std::max<size_t>(want, 256);
+  }
+  void release() {
+    if (p) {
+      (void)hipSetDevice(dev);
+      (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+    }
+  }
+  ~DevMem() { release(); }
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+struct Rank {
+  unsigned id = 0;
+  int device = 0;
+  hipStream_t compute = nullptr, xchg = nullptr;
+  hipEvent_t ev_start = nullptr, ev_part_r = nullptr, ev_part_s = nullptr, ev_cnt_r = nullptr, ev_cnt_s = nullptr,
+             ev_x0 = nullptr, ev_xr = nullptr, ev_xs = nullptr, ev_build0 = nullptr, ev_build = nullptr,
+             ev_probe0 = nullptr, ev_done = nullptr;
+  size_t lo = 0, n_local = 0;
+  DevMem build, probe;              // input shards
+  DevMem pk_r, pr_r, pk_s, pr_s;    // bucket-major (key, global row id) of both relations
+  DevMem cnt_dev;                   // [0,P) R send counts, [P,2P) S send counts
+  DevMem mat_dev;                   // gathered P x P matrices (R then S), row = sender
+  uint64_t *mat_host = nullptr;     // pinned copy
+  DevMem part_ws;
+  size_t part_ws_bytes = 0;
+  DevMem rk, rr, sk, sr;            // received pairs
+  DevMem join_ws, ids, pos, cnt;
+  size_t recv_r = 0, recv_s = 0;
+  DevMem chk;                       // validator results / conservation sums
+  ncclComm_t comm = nullptr;
+};
+
+template <class T>
+std::vector<T> d2h(const void *src, size_t count, int dev) {
+  std::vector<T> h(count);
+  hip_ok(hipSetDevice(dev), "hipSetDevice");
+  if (count) hip_ok(hipMemcpy(h.data(), src, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+  return h;
+}
+
+double span_us(hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0;
+  return ms * 1000.0;
+}
+
+}  // namespace
+
+struct Engine::Impl {
+  size_t n = 0;
+  Options opt;
+  unsigned P = 1;
+  bool rccl = false;
+  bool direct = false;
+  std::vector<std::unique_ptr<Rank>> ranks;  // the LOCAL ranks
+  bool planned = false;
+  int home = 0;
+
+  Rank &local(unsigned i) { return *ranks[i]; }
+  void set(const Rank &k) { hip_ok(hipSetDevice(k.device), "hipSetDevice"); }
+
+  void sync_all() {
+    for (auto &k : ranks) {
+      set(*k);
+      hip_ok(hipStreamSynchronize(k->compute), "hipStreamSynchronize");
+      hip_ok(hipStreamSynchronize(k->xchg), "hipStreamSynchronize");
+    }
+  }
+
+  // ---- the P x P count matrix of one relation (row = sender) reaches every local rank's pinned buffer ----------
+  void gather_counts(unsigned rel) {
+    if (rccl) {
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (auto &k : ranks) {
+        set(*k);
+        nccl_ok(ncclAllGather(k->cnt_dev.as<uint64_t>() + rel * P, k->mat_dev.as<uint64_t>() + rel * P * P, P, ncclUint64,
+                              k->comm, k->xchg),
+                "ncclAllGather");
+      }
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      for (auto &k : ranks) {
+        set(*k);
+        hip_ok(hipMemcpyAsync(k->mat_host + rel * P * P, k->mat_dev.as<uint64_t>() + rel * P * P, P * P * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, k->xchg),
+               "hipMemcpyAsync");
+      }
+    } else {  // ranks of one process without RCCL: every rank's row straight into every local rank's pinned matrix
+      for (auto &src : ranks) {
+        set(*src);
+        for (auto &dst : ranks)
+          hip_ok(hipMemcpyAsync(dst->mat_host + rel * P * P + static_cast<size_t>(src->id) * P,
+                                src->cnt_dev.as<uint64_t>() + rel * P, P * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                src->xchg),
+                 "hipMemcpyAsync");
+      }
+    }
+  }
+
+  // rows rank `q` sends to rank `r` in relation `rel`, from rank k's pinned matrix
+  static uint64_t cell(const Rank &k, unsigned P, unsigned rel, unsigned q, unsigned r) {
+    return k.mat_host[static_cast<size_t>(rel) * P * P + static_cast<size_t>(q) * P + r];
+  }
+
+  void size_receives(unsigned rel) {
+    for (auto &k : ranks) {
+      size_t total = 0;
+      for (unsigned q = 0; q < P; ++q) total += cell(*k, P, rel, q, k->id);
+      (rel == 0 ? k->recv_r : k->recv_s) = total;
+      DevMem &keys = rel == 0 ? k->rk : k->sk, &rids = rel == 0 ? k->rr : k->sr;
+      if (total * 4 > keys.bytes || total * 4 > rids.bytes) {  // steady state never grows: plan() left headroom
+        sync_all();
+        keys.reserve(k->device, total * 4 + total / 16 * 4);
+        rids.reserve(k->device, total * 4 + total / 16 * 4);
+      }
+      if (rel == 0) {
+        const size_t need = dbhip_join_workspace_bytes(total);
+        if (need > k->join_ws.bytes || total * 4 > k->ids.bytes) {
+          sync_all();
+          k->join_ws.reserve(k->device, need + need / 16);
+          k->ids.reserve(k->device, total * 4 + total / 16 * 4);
+        }
+      } else if (total * 4 > k->pos.bytes) {
+        sync_all();
+        k->pos.reserve(k->device, total * 4 + total / 16 * 4);
+        k->cnt.reserve(k->device, total * 4 + total / 16 * 4);
+      }
+    }
+  }
+
+  // ---- exchange of one relation: bucket d of every rank goes to rank d ---------------------------------------------
+  void exchange(unsigned rel) {
+    if (rccl) nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (auto &kp : ranks) {
+      Rank &me = *kp;
+      set(me);
+      const uint32_t *src_k = (rel == 0 ? me.pk_r : me.pk_s).as<uint32_t>();
+      const uint32_t *src_r = (rel == 0 ? me.pr_r : me.pr_s).as<uint32_t>();
+      uint32_t *dst_k = (rel == 0 ? me.rk : me.sk).as<uint32_t>();
+      uint32_t *dst_r = (rel == 0 ? me.rr : me.sr).as<uint32_t>();
+      uint64_t send_off = 0, recv_off = 0;
+      for (unsigned q = 0; q < P; ++q) {
+        const uint64_t send_cnt = cell(me, P, rel, me.id, q), recv_cnt = cell(me, P, rel, q, me.id);
+        if (rccl) {
+          for (int col = 0; col < 2; ++col) {
+            const uint32_t *s = (col ? src_r : src_k) + send_off;
+            uint32_t *d = (col ? dst_r : dst_k) + recv_off;
+            for (uint64_t o = 0; o < send_cnt; o += kPiece)
+              nccl_ok(ncclSend(s + o, std::min(kPiece, send_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
+                      "ncclSend");
+            for (uint64_t o = 0; o < recv_cnt; o += kPiece)
+              nccl_ok(ncclRecv(d + o, std::min(kPiece, recv_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
+                      "ncclRecv");
+          }
+        } else if (send_cnt) {  // push into the peer's receive buffers (the peer is a local rank in this mode)
+          Rank *peer = nullptr;
+          for (auto &c : ranks)
+            if (c->id == q) peer = c.get();
+          uint64_t peer_off = 0;  // where my segment starts on the peer: rows of the senders before me
+          for (unsigned w = 0; w < me.id; ++w) peer_off += cell(me, P, rel, w, q);
+          uint32_t *pk = (rel == 0 ? peer->rk : peer->sk).as<uint32_t>() + peer_off;
+          uint32_t *pr = (rel == 0 ? peer->rr : peer->sr).as<uint32_t>() + peer_off;
+          hip_ok(hipMemcpyPeerAsync(pk, peer->device, src_k + send_off, me.device, send_cnt * 4, me.xchg), "hipMemcpyPeerAsync");
+          hip_ok(hipMemcpyPeerAsync(pr, peer->device, src_r + send_off, me.device, send_cnt * 4, me.xchg), "hipMemcpyPeerAsync");
+        }
+        send_off += send_cnt;
+        recv_off += recv_cnt;
+      }
+    }
+    if (rccl) nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  }
+
+  void partition(Rank &k, unsigned rel) {
+    set(k);
+    const uint32_t *src = (rel == 0 ? k.build : k.probe).as<uint32_t>();
+    db_ok(dbhip_pjoin_partition_u32(src, k.n_local, k.lo, P, (rel == 0 ? k.pk_r : k.pk_s).as<uint32_t>(),
+                                    (rel == 0 ? k.pr_r : k.pr_s).as<uint32_t>(), k.cnt_dev.as<uint64_t>() + rel * P,
+                                    k.part_ws.p, k.part_ws_bytes, k.compute),
+          "dbhip_pjoin_partition_u32");
+  }
+};
+
+Engine::Engine(size_t n_total, const Options &opts) : impl_(new Impl) {
+  Impl &m = *impl_;
+  m.n = n_total;
+  m.opt = opts;
+  m.P = opts.world ? opts.world : 1;
+  if (m.P > 256) fail("partitioned join: at most 256 ranks");
+  if (n_total > 0xFFFFFFFFull) fail("partitioned join: global row ids must fit 32 bits");
+  m.direct = m.P == 1 && opts.direct_single;
+  int ndev = 0;
+  hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+  if (ndev < 1) fail("partitioned join: no HIP device");
+  (void)hipGetDevice(&m.home);
+  const unsigned first = opts.all_local ? 0 : opts.rank, count = opts.all_local ? m.P : 1;
+  if (!opts.all_local && opts.rank >= m.P) fail("partitioned join: rank out of range");
+  // a rank of a multi-process job talks RCCL as soon as it has a peer (or when the caller passes an id with world == 1:
+  // the one-rank rehearsal of the ncclCommInitRank / ncclAllGather / ncclAllReduce path)
+  m.rccl = opts.all_local ? (static_cast<int>(m.P) <= ndev && !opts.force_copy) : (m.P > 1 || opts.nccl_id != nullptr);
+  if (m.direct) m.rccl = false;
+  const uint32_t key_hi = static_cast<uint32_t>(n_total ? n_total - 1 : 0);
+  for (unsigned i = 0; i < count; ++i) {
+    auto k = std::make_unique<Rank>();
+    k->id = first + i;
+    k->device = opts.all_local ? static_cast<int>(k->id) % ndev : opts.device;
+    hip_ok(hipSetDevice(k->device), "hipSetDevice");
+    hip_ok(hipStreamCreateWithFlags(&k->compute, hipStreamNonBlocking), "hipStreamCreate");
+    hip_ok(hipStreamCreateWithFlags(&k->xchg, hipStreamNonBlocking), "hipStreamCreate");
+    for (hipEvent_t *e : {&k->ev_start, &k->ev_part_r, &k->ev_part_s, &k->ev_cnt_r, &k->ev_cnt_s, &k->ev_x0, &k->ev_xr,
+                          &k->ev_xs, &k->ev_build0, &k->ev_build, &k->ev_probe0, &k->ev_done})
+      hip_ok(hipEventCreate(e), "hipEventCreate");
+    const size_t per = n_total / m.P;
+    k->lo = static_cast<size_t>(k->id) * per;
+    k->n_local = (k->id == m.P - 1) ? n_total - k->lo : per;
+    const size_t col = k->n_local * sizeof(uint32_t);
+    k->build.reserve(k->device, col);
+    k->probe.reserve(k->device, col);
+    k->chk.reserve(k->device, 64 * sizeof(uint64_t));
+    db_ok(dbhip_gen_uniform_u32(k->build.as<uint32_t>(), k->n_local, opts.build_seed, k->lo, 0, key_hi, k->compute), "gen build");
+    db_ok(dbhip_gen_uniform_u32(k->probe.as<uint32_t>(), k->n_local, opts.probe_seed, k->lo, 0, key_hi, k->compute), "gen probe");
+    if (!m.direct) {
+      k->pk_r.reserve(k->device, col);
+      k->pr_r.reserve(k->device, col);
+      k->pk_s.reserve(k->device, col);
+      k->pr_s.reserve(k->device, col);
+      k->cnt_dev.reserve(k->device, 2 * m.P * sizeof(uint64_t));
+      k->mat_dev.reserve(k->device, 2 * static_cast<size_t>(m.P) * m.P * sizeof(uint64_t));
+      hip_ok(hipHostMalloc(reinterpret_cast<void **>(&k->mat_host), 2 * static_cast<size_t>(m.P) * m.P * sizeof(uint64_t),
+                           hipHostMallocDefault),
+             "hipHostMalloc");
+      k->part_ws_bytes = dbhip_pjoin_partition_workspace_bytes(k->n_local, m.P);
+      k->part_ws.reserve(k->device, k->part_ws_bytes);
+    }
+    m.ranks.push_back(std::move(k));
+  }
+  if (m.rccl) {
+    if (opts.all_local) {
+      std::vector<int> devs(m.P);
+      std::vector<ncclComm_t> comms(m.P);
+      for (unsigned r = 0; r < m.P; ++r) devs[r] = m.ranks[r]->device;
+      nccl_ok(ncclCommInitAll(comms.data(), static_cast<int>(m.P), devs.data()), "ncclCommInitAll");
+      for (unsigned r = 0; r < m.P; ++r) m.ranks[r]->comm = comms[r];
+    } else {
+      if (!opts.nccl_id) fail("partitioned join: a rank of a multi-process job needs the shared ncclUniqueId");
+      ncclUniqueId id;
+      std::memcpy(&id, opts.nccl_id, sizeof(id));
+      m.set(*m.ranks[0]);
+      nccl_ok(ncclCommInitRank(&m.ranks[0]->comm, static_cast<int>(m.P), id, static_cast<int>(opts.rank)), "ncclCommInitRank");
+    }
+  } else if (!m.direct) {
+    for (auto &a : m.ranks)
+      for (auto &b : m.ranks)
+        if (a->device != b->device) {
+          m.set(*a);
+          const hipError_t e = hipDeviceEnablePeerAccess(b->device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_ok(e, "hipDeviceEnablePeerAccess");
+          (void)hipGetLastError();
+        }
+  }
+  m.sync_all();
+}
+
+Engine::~Engine() {
+  if (!impl_) return;
+  Impl &m = *impl_;
+  for (auto &k : m.ranks) {
+    (void)hipSetDevice(k->device);
+    (void)hipStreamSynchronize(k->compute);
+    (void)hipStreamSynchronize(k->xchg);
+    if (k->comm) (void)ncclCommDestroy(k->comm);
+    for (hipEvent_t e : {k->ev_start, k->ev_part_r, k->ev_part_s, k->ev_cnt_r, k->ev_cnt_s, k->ev_x0, k->ev_xr, k->ev_xs,
+                         k->ev_build0, k->ev_build, k->ev_probe0, k->ev_done})
+      if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(k->compute);
+    (void)hipStreamDestroy(k->xchg);
+    if (k->mat_host) (void)hipHostFree(k->mat_host);
+  }
+  m.ranks.clear();
+  (void)hipSetDevice(m.home);
+}
+
+unsigned Engine::world() const { return impl_->P; }
+unsigned Engine::local_ranks() const { return static_cast<unsigned>(impl_->ranks.size()); }
+bool Engine::uses_rccl() const { return impl_->rccl; }
+size_t Engine::n_total() const { return impl_->n; }
+
+void Engine::plan() {
+  Impl &m = *impl_;
+  if (m.direct) {
+    Rank &k = m.local(0);
+    k.recv_r = k.recv_s = k.n_local;
+    k.join_ws.reserve(k.device, dbhip_join_workspace_bytes(k.n_local));
+    k.ids.reserve(k.device, k.n_local * 4);
+    k.pos.reserve(k.device, k.n_local * 4);
+    k.cnt.reserve(k.device, k.n_local * 4);
+    m.planned = true;
+    return;
+  }
+  // one partition pass of both relations: the receive sizes of the steady state (+ 1/16 headroom: the same data
+  // gives the same sizes every step, so nothing is allocated inside a timed step)
+  for (auto &k : m.ranks) {
+    m.partition(*k, 0);
+    m.partition(*k, 1);
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_part_s, k->compute), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(k->xchg, k->ev_part_s, 0), "hipStreamWaitEvent");
+  }
+  m.gather_counts(0);
+  m.gather_counts(1);
+  m.sync_all();
+  m.size_receives(0);
+  m.size_receives(1);
+  m.planned = true;
+}
+
+StepTimes Engine::step() {
+  Impl &m = *impl_;
+  if (!m.planned) plan();
+  StepTimes t;
+  const auto t0 = clk::now();
+  if (m.direct) {
+    Rank &k = m.local(0);
+    m.set(k);
+    hip_ok(hipEventRecord(k.ev_start, k.compute), "hipEventRecord");
+    db_ok(dbhip_join_build_u32(k.build.as<uint32_t>(), k.n_local, k.ids.as<uint32_t>(), k.join_ws.p, k.join_ws.bytes, k.compute),
+          "dbhip_join_build_u32");
+    hip_ok(hipEventRecord(k.ev_build, k.compute), "hipEventRecord");
+    db_ok(dbhip_join_probe_u32(k.probe.as<uint32_t>(), k.n_local, k.join_ws.p, k.n_local, k.pos.as<uint32_t>(),
+                               k.cnt.as<uint32_t>(), k.compute),
+          "dbhip_join_probe_u32");
+    hip_ok(hipEventRecord(k.ev_done, k.compute), "hipEventRecord");
+    hip_ok(hipEventSynchronize(k.ev_build), "hipEventSynchronize");
+    t.until_build_done = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+    hip_ok(hipStreamSynchronize(k.compute), "hipStreamSynchronize");
+    t.total = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+    t.build = span_us(k.ev_start, k.ev_build);
+    t.probe = span_us(k.ev_build, k.ev_done);
+    return t;
+  }
+  // ---- R: partition on the compute stream; its counts and its exchange on the exchange stream
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_start, k->compute), "hipEventRecord");
+    m.partition(*k, 0);
+    hip_ok(hipEventRecord(k->ev_part_r, k->compute), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(k->xchg, k->ev_part_r, 0), "hipStreamWaitEvent");
+  }
+  m.gather_counts(0);
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_cnt_r, k->xchg), "hipEventRecord");
+    // ---- S: partitioned while R's counts travel and R is on the links
+    m.partition(*k, 1);
+    hip_ok(hipEventRecord(k->ev_part_s, k->compute), "hipEventRecord");
+  }
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventSynchronize(k->ev_cnt_r), "hipEventSynchronize");  // host wait 1: R's receive sizes
+  }
+  m.size_receives(0);
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_x0, k->xchg), "hipEventRecord");
+  }
+  m.exchange(0);
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_xr, k->xchg), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(k->xchg, k->ev_part_s, 0), "hipStreamWaitEvent");
+  }
+  m.gather_counts(1);
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_cnt_s, k->xchg), "hipEventRecord");
+  }
+  // ---- build on the received R pairs (while S's counts travel and S goes onto the links).  Without RCCL a rank's
+  // receive buffers are filled by the OTHER ranks' streams: wait for every sender.
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    if (m.rccl) {
+      hip_ok(hipStreamWaitEvent(k->compute, k->ev_xr, 0), "hipStreamWaitEvent");
+    } else {
+      for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xr, 0), "hipStreamWaitEvent");
+    }
+    hip_ok(hipEventRecord(k->ev_build0, k->compute), "hipEventRecord");
+    db_ok(dbhip_join_build_pairs_u32(k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->ids.as<uint32_t>(), k->join_ws.p,
+                                     k->join_ws.bytes, k->compute),
+          "dbhip_join_build_pairs_u32");
+    hip_ok(hipEventRecord(k->ev_build, k->compute), "hipEventRecord");
+  }
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventSynchronize(k->ev_cnt_s), "hipEventSynchronize");  // host wait 2: S's receive sizes
+  }
+  m.size_receives(1);
+  m.exchange(1);
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventRecord(k->ev_xs, k->xchg), "hipEventRecord");
+  }
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    if (m.rccl) {
+      hip_ok(hipStreamWaitEvent(k->compute, k->ev_xs, 0), "hipStreamWaitEvent");
+    } else {
+      for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xs, 0), "hipStreamWaitEvent");
+    }
+    hip_ok(hipEventRecord(k->ev_probe0, k->compute), "hipEventRecord");
+    db_ok(dbhip_join_probe_u32(k->sk.as<uint32_t>(), k->recv_s, k->join_ws.p, k->recv_r, k->pos.as<uint32_t>(),
+                               k->cnt.as<uint32_t>(), k->compute),
+          "dbhip_join_probe_u32");
+    hip_ok(hipEventRecord(k->ev_done, k->compute), "hipEventRecord");
+  }
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    hip_ok(hipEventSynchronize(k->ev_build), "hipEventSynchronize");
+  }
+  t.until_build_done = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+  m.sync_all();
+  t.total = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+  for (auto &k : m.ranks) {
+    m.set(*k);
+    t.partition = std::max(t.partition, span_us(k->ev_start, k->ev_part_s));
+    t.exchange = std::max(t.exchange, span_us(k->ev_x0, k->ev_xs));
+    t.build = std::max(t.build, span_us(k->ev_build0, k->ev_build));
+    t.probe = std::max(t.probe, span_us(k->ev_probe0, k->ev_done));
+  }
+  return t;
+}
+
+CheckReport Engine::check() {
+  Impl &m = *impl_;
+  CheckReport rep;
+  const uint32_t key_hi = static_cast<uint32_t>(m.n ? m.n - 1 : 0);
+  for (auto &kp : m.ranks) {
+    Rank &k = *kp;
+    m.set(k);
+    uint64_t *res = k.chk.as<uint64_t>();
+    hipStream_t s = k.compute;
+    const uint32_t *bkeys = m.direct ? k.build.as<uint32_t>() : k.rk.as<uint32_t>();
+    const uint32_t *pkeys = m.direct ? k.probe.as<uint32_t>() : k.sk.as<uint32_t>();
+    if (!m.direct) {
+      // conservation sums: everything partitioned here (= sent, to others and to itself) and everything received
+      const void *cols[8] = {k.pk_r.p, k.pr_r.p, k.pk_s.p, k.pr_s.p, k.rk.p, k.rr.p, k.sk.p, k.sr.p};
+      const size_t lens[8] = {k.n_local, k.n_local, k.n_local, k.n_local, k.recv_r, k.recv_r, k.recv_s, k.recv_s};
+      int32_t *sums = reinterpret_cast<int32_t *>(res + 32);
+      for (int c = 0; c < 8; ++c)
+        db_ok(dbhip_reduce_sum_i32(static_cast<const int32_t *>(cols[c]), lens[c], sums + c, s), "dbhip_reduce_sum_i32");
+      // received pairs are what the generator produced for their global row id; received keys hash to this rank
+      db_ok(dbhip_check_gen_uniform_u32(k.rk.as<uint32_t>(), k.rr.as<uint32_t>(), k.recv_r, m.opt.build_seed, 0, 0, key_hi,
+                                        res + 0, s), "dbhip_check_gen_uniform_u32");
+      db_ok(dbhip_check_gen_uniform_u32(k.sk.as<uint32_t>(), k.sr.as<uint32_t>(), k.recv_s, m.opt.probe_seed, 0, 0, key_hi,
+                                        res + 1, s), "dbhip_check_gen_uniform_u32");
+      db_ok(dbhip_check_pjoin_route_u32(k.rk.as<uint32_t>(), k.recv_r, m.P, k.id, res + 2, s), "dbhip_check_pjoin_route_u32");
+      db_ok(dbhip_check_pjoin_route_u32(k.sk.as<uint32_t>(), k.recv_s, m.P, k.id, res + 3, s), "dbhip_check_pjoin_route_u32");
+    }
+    // per probe row: count == multiplicity of the key among the build keys this rank joined (sorted copy, binary
+    // search), id range inside the id buffer, sampled ids carry the key (regenerated from the GLOBAL row id)
+    DevMem sorted, tmp, sort_ws;
+    sorted.reserve(k.device, k.recv_r * 4);
+    tmp.reserve(k.device, k.recv_r * 4);
+    const size_t sort_bytes = dbhip_radix_sort_workspace_bytes(k.recv_r, 8);
+    sort_ws.reserve(k.device, sort_bytes);
+    if (k.recv_r) {
+      hip_ok(hipMemcpyAsync(sorted.p, bkeys, k.recv_r * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+      db_ok(dbhip_radix_sort_u32(sorted.as<uint32_t>(), tmp.as<uint32_t>(), k.recv_r, 8, sort_ws.p, sort_ws.bytes, s),
+            "dbhip_radix_sort_u32");
+    }
+    if (m.direct)  // local row indices: the key of an id is a lookup
+      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pkeys, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
+                                 k.ids.as<uint32_t>(), bkeys, 0, 0, 0, res + 4, s), "dbhip_check_join_u32");
+    else
+      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pkeys, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
+                                 k.ids.as<uint32_t>(), nullptr, m.opt.build_seed, 0, key_hi, res + 4, s), "dbhip_check_join_u32");
+    hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize");
+    const auto h = d2h<uint64_t>(res, 40, k.device);
+    if (!m.direct) {
+      rep.bad_pairs += h[0] + h[1];
+      rep.bad_route += h[2] + h[3];
+      const uint32_t *sums = reinterpret_cast<const uint32_t *>(h.data() + 32);
+      for (int c = 0; c < 4; ++c) {
+        rep.sent_sum[c] += sums[c];
+        rep.recv_sum[c] += sums[4 + c];
+      }
+      rep.sent_rows += 2 * k.n_local - Impl::cell(k, m.P, 0, k.id, k.id) - Impl::cell(k, m.P, 1, k.id, k.id);
+    }
+    rep.bad_rows += h[4];
+    rep.matches += h[5];
+    rep.recv_build += k.recv_r;
+    rep.recv_probe += k.recv_s;
+  }
+  return rep;
+}
+
+bool Engine::conserved(const CheckReport &local) {
+  Impl &m = *impl_;
+  uint32_t sums[8];
+  for (int c = 0; c < 4; ++c) {
+    sums[c] = local.sent_sum[c];
+    sums[4 + c] = local.recv_sum[c];
+  }
+  if (m.rccl && !m.opt.all_local) {  // the other ranks' sums live in other processes
+    Rank &k = m.local(0);
+    m.set(k);
+    uint32_t *dev = reinterpret_cast<uint32_t *>(k.chk.as<uint64_t>() + 48);
+    hip_ok(hipMemcpyAsync(dev, sums, sizeof(sums), hipMemcpyHostToDevice, k.xchg), "hipMemcpyAsync");
+    nccl_ok(ncclAllReduce(dev, dev, 8, ncclUint32, ncclSum, k.comm, k.xchg), "ncclAllReduce");
+    hip_ok(hipMemcpyAsync(sums, dev, sizeof(sums), hipMemcpyDeviceToHost, k.xchg), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(k.xchg), "hipStreamSynchronize");
+  }
+  for (int c = 0; c < 4; ++c)
+    if (sums[c] != sums[4 + c]) return false;
+  return true;
+}
+
+Engine::HostShard Engine::download(unsigned i) const {
+  Impl &m = *impl_;
+  Rank &k = m.local(i);
+  HostShard h;
+  if (m.direct) {
+    h.probe_keys = d2h<uint32_t>(k.probe.p, k.n_local, k.device);
+    h.probe_row_ids.resize(k.n_local);
+    for (size_t j = 0; j < k.n_local; ++j) h.probe_row_ids[j] = static_cast<uint32_t>(k.lo + j);
+  } else {
+    h.probe_keys = d2h<uint32_t>(k.sk.p, k.recv_s, k.device);
+    h.probe_row_ids = d2h<uint32_t>(k.sr.p, k.recv_s, k.device);
+  }
+  h.pos = d2h<uint32_t>(k.pos.p, k.recv_s, k.device);
+  h.cnt = d2h<uint32_t>(k.cnt.p, k.recv_s, k.device);
+  h.ids = d2h<uint32_t>(k.ids.p, k.recv_r, k.device);
+  return h;
+}
+
+void Engine::corrupt_one_count() {
+  for (auto &k : impl_->ranks) {
+    if (!k->recv_s) continue;
+    impl_->set(*k);
+    uint32_t h = 0;
+    uint32_t *w = k->cnt.as<uint32_t>() + k->recv_s / 2;
+    hip_ok(hipMemcpy(&h, w, sizeof(h), hipMemcpyDeviceToHost), "poke D2H");
+    h ^= 1u;
+    hip_ok(hipMemcpy(w, &h, sizeof(h), hipMemcpyHostToDevice), "poke H2D");
+    return;
+  }
+}
+
+std::vector<uint32_t> Engine::download_column(unsigned i, bool build) const {
+  Rank &k = impl_->local(i);
+  return d2h<uint32_t>(build ? k.build.p : k.probe.p, k.n_local, k.device);
+}
+
+}  // namespace pjoin
+
+// ---- C entry points ---------------------------------------------------------------------------------------------
+extern "C" int dbench_pjoin_unique_id(char *out128) {
+  if (!out128) return -1;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -2;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned world, int device, const char *id128,
+                                     int direct_single) {
+  try {
+    pjoin::Options o;
+    o.world = world;
+    o.all_local = false;
+    o.rank = rank;
+    o.device = device;
+    o.nccl_id = id128;
+    o.direct_single = direct_single != 0;
+    auto *e = new pjoin::Engine(static_cast<size_t>(n_total), o);
+    e->plan();
+    return e;
+  } catch (const std::exception &ex) {
+    std::cerr << "dbench_pjoin_create: " << ex.what() << std::endl;
+    return nullptr;
+  }
+}
+
+extern "C" int dbench_pjoin_step(void *handle, double *times_us) {
+  if (!handle) return -1;
+  try {
+    const pjoin::StepTimes t = static_cast<pjoin::Engine *>(handle)->step();
+    if (times_us) {
+      const double v[6] = {t.total, t.partition, t.exchange, t.build, t.probe, t.until_build_done};
+      std::memcpy(times_us, v, sizeof(v));
+    }
+    return 0;
+  } catch (const std::exception &ex) {
+    std::cerr << "dbench_pjoin_step: " << ex.what() << std::endl;
+    return -2;
+  }
+}
+
+extern "C" int dbench_pjoin_check(void *handle, uint64_t *words) {
+  if (!handle || !words) return -1;
+  try {
+    auto *e = static_cast<pjoin::Engine *>(handle);
+    const pjoin::CheckReport r = e->check();
+    const bool ok = e->conserved(r);
+    const uint64_t v[16] = {r.bad_pairs, r.bad_route, r.bad_rows, r.matches, r.recv_build, r.recv_probe, r.sent_rows, ok ? 1u : 0u,
+                            r.sent_sum[0], r.sent_sum[1], r.sent_sum[2], r.sent_sum[3],
+                            r.recv_sum[0], r.recv_sum[1], r.recv_sum[2], r.recv_sum[3]};
+    std::memcpy(words, v, sizeof(v));
+    return 0;
+  } catch (const std::exception &ex) {
+    std::cerr << "dbench_pjoin_check: " << ex.what() << std::endl;
+    return -2;
+  }
+}
+
+extern "C" void dbench_pjoin_destroy(void *handle) { delete static_cast<pjoin::Engine *>(handle); }

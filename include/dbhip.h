@@ -191,6 +191,10 @@ int dbhip_pjoin_partition_u32(const uint32_t *keys, size_t n, uint64_t first_row
                               void *workspace, size_t workspace_bytes, dbhip_stream_t stream);
 int dbhip_gather_u32(const uint32_t *table, const uint32_t *idx, size_t n, uint32_t *out,
                      dbhip_stream_t stream);
+/* validator of the exchange's routing: result[0] (DEVICE uint64) = number of keys that dbhip_pjoin_partition_u32
+ * would NOT put into bucket `rank` of `parts` (0 on a rank that received only its own keys)            */
+int dbhip_check_pjoin_route_u32(const uint32_t *keys, size_t n, uint32_t parts, uint32_t rank, uint64_t *result,
+                                dbhip_stream_t stream);
 
 /* ---- the two small dwarfs that complete the taxonomy ---------------------------
  * dbhip_reduce_sum_i32: *out = sum of src[0..n) with int32 wrap-around (reduce/reduce.cpp:27-88, the

@@ -62,6 +62,7 @@ def test_partitioned_join_dwarf(gpus, env):
     assert r.returncode == 0, r.stderr
     assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
     assert r.stdout.count("Build time:") == 3 * 5 and r.stdout.count("Exchange time:") == 3 * 5
+    assert r.stdout.count("Local probe time:") == 3 * 5
     assert f"{gpus} rank(s) on 1 GPU(s)" in r.stdout
     want = "RCCL" if (gpus == "1" and not env) else "hipMemcpyPeerAsync"
     assert f"exchange by {want}" in r.stdout
@@ -162,3 +163,39 @@ def test_scan_host_time_with_transfers(tmp_path):
     with_copies, k1 = host_ms({"DWARF_BENCH_TIME_TRANSFERS": "1"})
     assert with_copies > resident + 1.5  # 128 MiB over PCIe gen5 x16 >= 2 ms; pageable copies take longer
     assert k1 < 1.0 and k0 < 1.0  # kernel_time is the same small figure either way
+
+
+def test_partitioned_join_rccl_messages_above_one_gib():
+    """n = 2^28 + 12345 rows through --gpus 1: the rank's RCCL self send/recv carries every column (> 1 GiB) as two
+    pieces of at most 2^28 elements.  A single 2 GiB ncclSend/ncclRecv once delivered garbage without an error: the
+    always-on conservation check and the device-side pair / routing / count checks must stay silent.  The log is
+    kept under gpurun_out/ (a copy is committed under profiles/)."""
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", "1", "--iterations", "1", "--input_size", "268447801"])
+    log = Path(__file__).resolve().parents[1] / "gpurun_out"
+    log.mkdir(exist_ok=True)
+    (log / "pjoin_rccl_two_pieces.txt").write_text(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    assert r.returncode == 0, r.stderr
+    assert "exchange by RCCL" in r.stdout
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 1
+
+
+@pytest.mark.parametrize("gpus,env", [("1", {}), ("4", {}), ("1", {"DWARF_BENCH_PJOIN_DIRECT": "1"})])
+def test_partitioned_join_fault_injection(gpus, env):
+    import os
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "2", "--input_size", "300007"],
+             env={**os.environ, **env, "DWARF_BENCH_INJECT_FAULT": "1"})
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("ncorrect results") >= 2, r.stderr
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "2", "--input_size", "300007"],
+             env={**os.environ, **env})
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
+
+
+def test_partitioned_join_above_the_host_check_limit():
+    """2^24 rows over 8 ranks sharing the GPU with the host-side check switched off: Result::valid rests on the
+    device-side checks alone (what a 2^30-row run relies on)"""
+    import os
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", "8", "--iterations", "2", "--input_size", "16777216"],
+             env={**os.environ, "DWARF_BENCH_VALIDATE_MAX": "1"})
+    assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
