@@ -6,11 +6,42 @@
 
 namespace dbhip {
 
-constexpr unsigned kJlSubSlots = 4096;  // slots of one LDS sub-table (48 KiB of LDS with counts/positions)
-constexpr unsigned kJlSubMask = kJlSubSlots - 1;
-constexpr unsigned kJlRowsPerPart = 2048;           // expected rows per partition (load factor <= 0.5)
+// Sub-table geometry (compile-time knobs for experiments).  A partition is expected to hold kJlRowsPerPart rows
+// (Poisson: +-6 sigma = +-270 at 2048) and owns kJlSubSlots slots of an LDS-resident open-addressing table: any
+// number of rows, at most kJlSubSlots DISTINCT keys.  3072 slots for 2048 rows: all-distinct keys (the unique-key
+// join) load the table to 0.67, the uniform one-to-many regime (63 % distinct) to 0.42; the table costs 12 bytes per
+// build row in HBM (4096 slots, the first geometry: 16).  Measured at 2^26 rows, whole build / probe: see DESIGN.md.
+#ifndef DBHIP_JL_SUB_SLOTS
+#define DBHIP_JL_SUB_SLOTS 3072
+#endif
+#ifndef DBHIP_JL_ROWS_PER_PART
+#define DBHIP_JL_ROWS_PER_PART 2048
+#endif
+constexpr unsigned kJlSubSlots = DBHIP_JL_SUB_SLOTS;          // slots of one LDS sub-table (a multiple of 512)
+constexpr unsigned kJlRowsPerPart = DBHIP_JL_ROWS_PER_PART;   // expected rows per partition
+static_assert(kJlSubSlots % 512 == 0 && kJlSubSlots <= 65536, "sub-table size");
 constexpr size_t kJlMinRows = static_cast<size_t>(1) << 16;  // unique-key join only: below, the CAS table of join.hip
-constexpr size_t kJlMaxRows = static_cast<size_t>(1) << 31;  // above: 2^20 partitions would overfill
+constexpr size_t kJlMaxRows = static_cast<size_t>(1) << 31;  // 32-bit row ids and id positions
+
+// slot of a key inside its sub-table, from the mixed hash h = fmix32(key): the partition is the HIGH log2(parts)
+// bits of h (up to 20), so the slot takes the top 16 bits of h * golden-ratio — every low bit of h reaches them, the
+// bits that are constant inside one partition do not pin them — range-reduced by multiply-shift; linear probing
+// wraps at kJlSubSlots
+__host__ __device__ __forceinline__ unsigned jl_home_slot(unsigned h) {
+  return (((h * 0x9E3779B1u) >> 16) * kJlSubSlots) >> 16;
+}
+__host__ __device__ __forceinline__ unsigned jl_next_slot(unsigned s) { return s + 1 == kJlSubSlots ? 0u : s + 1; }
+
+// One-to-many table slot = {key, first id position | (count field << pos_bits)}: the id positions of a build of n
+// rows need pos_bits = bit width of n; the bits above hold min(count - 1, escape) with escape = all ones.  A probe
+// that finds a smaller field has the count without a second access; the escape value (and pos_bits == 32) sends it
+// to the right-hand neighbour, whose first position ends this slot's id range (positions run on through empty slots
+// and from one sub-table to the next, closed by one sentinel slot).
+__host__ __device__ __forceinline__ unsigned jl_pos_bits(size_t n_build) {
+  unsigned b = 1;
+  while (b < 32 && (static_cast<size_t>(1) << b) <= n_build) ++b;
+  return b;
+}
 
 // The unique-key payload join keeps a plain CAS table in HBM below kJlMinRows build rows (fewer launches); the
 // one-to-many join takes the partitioned path at every size.  DBHIP_JOIN_PATH=lds|hbm overrides for experiments.
@@ -24,6 +55,9 @@ inline bool jl_use_ujoin(size_t n_build) {
   return n_build >= kJlMinRows && n_build <= kJlMaxRows;
 }
 
+#ifndef DBHIP_JL_K2_BIAS
+#define DBHIP_JL_K2_BIAS 0
+#endif
 struct JlLayout {
   unsigned parts, k1, k2, log2_k2;
   size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, total;
@@ -32,12 +66,12 @@ struct JlLayout {
 inline JlLayout jl_layout(size_t n) {
   JlLayout L;
   unsigned lg = 0;
-  while ((static_cast<size_t>(kJlRowsPerPart) << lg) < n && lg < 20) ++lg;
+  while ((static_cast<size_t>(kJlRowsPerPart) << lg) < n && lg < 20) ++lg;  // 2^20 partitions at most
   L.parts = 1u << lg;
   if (L.parts <= 1024) {  // one scatter level handles up to 1024 buckets
     L.log2_k2 = 0;
   } else {
-    L.log2_k2 = lg / 2;
+    L.log2_k2 = (lg + DBHIP_JL_K2_BIAS) / 2;  // split of the partition bits between the two scatter levels
   }
   L.k2 = 1u << L.log2_k2;
   L.k1 = L.parts / L.k2;

@@ -5,24 +5,26 @@
 // Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
 // — three per build row — and three 4-byte gathers per probe row (53 G/s).  LDS atomics run at
 // > 800 G/s.  So:
-//   build  1. partition the build column into K = n/2048 partitions by the HIGH bits of the mixed hash,
+//   build  1. partition the build column into K = n/4096 partitions by the HIGH bits of the mixed hash,
 //             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
-//             one global reservation per bucket per 4096-key tile, runs written contiguously);
-//          2. one workgroup per partition (jl_build): 4096-slot sub-table in LDS — ds_cmpst claim of
-//             the key slot by the LOW hash bits, ds_add count, LDS exclusive scan -> positions, second
-//             sweep over the partition's (L2-resident) rows fills ids, then the sub-table is written out
-//             as 8-byte slots {key, first id position} — EVERY slot, empty ones included, carries the
-//             position the exclusive scan reached there, and positions run on from one sub-table to the
-//             next (the global table is the concatenation of the sub-tables plus one sentinel slot
-//             {empty, n}), so a key's match count is first_position[slot + 1] - first_position[slot]
-//             and needs no field of its own: the table write, the largest item of the build's traffic,
-//             is 16n bytes instead of 32n;
-//   probe  one 16-byte gather per probe row = the slot and its right-hand neighbour (partition from the
-//          high hash bits, slot from the low bits, linear probing inside the 4096-slot sub-table),
-//          outputs written coalesced in row order.
-// A partition may hold any number of rows (duplicates do not matter); it may hold at most 4096
-// DISTINCT keys — with 2048 rows expected per partition and a mixing hash that is out of reach for
-// real data; if it happens the build sets DBHIP_DEV_TABLE_FULL.
+//             one global reservation per bucket per 4096-key tile, runs of (key, row id) pairs written
+//             contiguously);
+//          2. persistent workgroups walk the partitions (jl_build): 6144-slot sub-table in LDS — ds_cmpst
+//             claim of the key's slot, ds_add count, LDS exclusive scan -> positions, the fill takes slot and
+//             row id of each row from registers kept since the claim, then the sub-table is written out
+//             as 8-byte slots {key, first id position | count field} — EVERY slot, empty ones included,
+//             carries the position the exclusive scan reached there, and positions run on from one
+//             sub-table to the next (the global table is the concatenation of the sub-tables plus one
+//             sentinel slot {empty, n}), so a key's match count is ALSO first_position[slot + 1] -
+//             first_position[slot]; the bits of the position word that n does not need hold
+//             min(count - 1, all ones) (join_common.hpp): the table costs 12 bytes per build row;
+//   probe  ONE 8-byte gather per probe row whenever the count fits its field (a 16-byte read of slot and
+//          neighbour crossed a 64-byte line for every eighth row: one more memory request); the all-ones
+//          field sends the row to the right-hand neighbour.  Partition from the high hash bits, linear
+//          probing inside the sub-table, outputs written coalesced in row order.
+// A partition may hold any number of rows (duplicates do not matter); it may hold at most 6144
+// DISTINCT keys — with 4096 rows expected per partition (+-64 per sigma) and a mixing hash that is out of
+// reach for real data; if it happens the build sets DBHIP_DEV_TABLE_FULL.
 #include "dbhip_common.hpp"
 #include "join_common.hpp"
 
@@ -329,7 +331,7 @@ __device__ __forceinline__ bool jl_locate(const unsigned long long *__restrict__
 // lane per step), so a bucket's k2 counters see 16 flushes instead of one per scatter tile
 constexpr unsigned kJlHist1WgPerBucket = 16;
 
-__global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__restrict__ keys,
+__global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const u32x2 *__restrict__ rows,
                                                               const unsigned long long *__restrict__ starts0,
                                                               unsigned parts, unsigned k2,
                                                               unsigned long long *counts1) {
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__
   __syncthreads();
   for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlThreads + threadIdx.x; i < hi;
        i += static_cast<size_t>(kJlHist1WgPerBucket) * 4 * kJlThreads) {
-    unsigned k[4];
+    unsigned k[4];  // the level-0 output is (key, row id) pairs: the histogram reads them whole (8 bytes per row)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlThreads < hi ? keys[i + j * kJlThreads] : 0u;
+    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlThreads < hi ? rows[i + j * kJlThreads].x : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts) & (k2 - 1)], 1u);
@@ -353,8 +355,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const unsigned *__
     if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
 }
 
-__global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned *__restrict__ keys,
-                                                                 const unsigned *__restrict__ rids,
+__global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const u32x2 *__restrict__ rows,
                                                                  const unsigned long long *__restrict__ starts0,
                                                                  const unsigned long long *__restrict__ tile_starts,
                                                                  unsigned parts, unsigned k1, unsigned k2,
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const unsigned 
   for (int j = 0; j < kJlKpt; ++j) {
     const size_t idx = lo + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
     const bool valid = idx < hi && idx < lo + kJlTile;
-    key[j] = valid ? keys[idx] : 0u;
-    rid[j] = valid ? rids[idx] : 0u;
+    const u32x2 row = valid ? rows[idx] : u32x2{0u, 0u};
+    key[j] = row.x;
+    rid[j] = row.y;
     dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
   }
   jl_scatter_tile<1>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
@@ -388,21 +390,52 @@ __device__ __forceinline__ u32x2 jl_row(const unsigned *__restrict__ pkeys, cons
   return reinterpret_cast<const u32x2 *>(pkeys)[i];
 }
 
+// Slot of `key` in the LDS key array `lk`: a plain read first — a key that is already there (a duplicate row) and
+// every step of a collision chain need no atomic — ds_cmpst only on a slot read as empty.  Returns kJlSubSlots for
+// the sentinel key (flagged) and for a full table (flagged).
+__device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigned *status) {
+  if (key == kEmptyKey) {  // the sentinel is not a key (join/join_omnisci.cpp:52): flag it, drop the row
+    atomicOr(status, DBHIP_DEV_KEY_RANGE);
+    return kJlSubSlots;
+  }
+  unsigned s = jl_home_slot(fmix32(key));
+  for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
+    unsigned k = lk[s];
+    if (k == kEmptyKey) k = atomicCAS(&lk[s], kEmptyKey, key);
+    if (k == kEmptyKey || k == key) return s;
+    s = jl_next_slot(s);
+  }
+  atomicOr(status, DBHIP_DEV_TABLE_FULL);
+  return kJlSubSlots;
+}
+
+// Barriers of the build kernel order LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the
+// next partition's prefetched rows and for every id / table store still on its way to memory (DBHIP_JL_FULL_BARRIER=1
+// restores it for A/B timing).
+#ifdef DBHIP_JL_FULL_BARRIER
+#define JL_BUILD_BARRIER() __syncthreads()
+#else
+#define JL_BUILD_BARRIER() wg_barrier_lds_only()
+#endif
 __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
                                                                    u32x2 *__restrict__ table, unsigned parts,
-                                                                   unsigned n_rows,
+                                                                   unsigned n_rows, unsigned pos_bits,
                                                                    unsigned *__restrict__ ids, unsigned *status) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
   unsigned *lk = s_lds;                // keys
   unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
   unsigned *lp = lc;                   // first id position of the slot, bumped to its end by the fill.
-  // (two 16 KiB arrays instead of three: 4 workgroups per CU instead of 3)
+  // (two arrays instead of three: 48 KiB per workgroup at 6144 slots, three workgroups per CU)
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
+  __shared__ unsigned s_end;  // where the last slot's id range ends = first position behind the partition's counted rows
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  constexpr int kJlCached = 8;  // rows per thread whose slot and row id stay in registers between steps 1 and 3
-  constexpr int kJlPre = 4;     // rows per thread loaded one partition ahead (a partition holds ~2048 rows = 4 per thread)
+  // a partition holds ~kJlRowsPerPart rows (+ 6 sigma of a Poisson count): rows per thread whose slot and row id
+  // stay in registers between steps 1 and 3, and rows per thread loaded one partition ahead
+  constexpr int kJlCached = static_cast<int>((kJlRowsPerPart + kJlRowsPerPart / 8 + kJlBuildThreads - 1) / kJlBuildThreads);
+  constexpr int kJlPre = static_cast<int>(kJlRowsPerPart / kJlBuildThreads);
+  static_assert(static_cast<unsigned>(kJlCached) * kJlBuildThreads <= kJlSubSlots, "a partition without overflow rows fits the id staging area");
 
   // Persistent workgroups walk the partitions with a stride of the grid; a workgroup is a chain of dependent
   // phases (load, claim, scan, fill, publish), so the NEXT partition's rows are requested before the current
@@ -435,62 +468,41 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
         pre[r] = i < nhi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
       }
     }
-    __syncthreads();
-    // 1. claim the key's slot (ds_cmpst) and count the row (ds_add)
-    unsigned c_slot[kJlCached], c_rid[kJlCached];
+    JL_BUILD_BARRIER();
+    // 1. claim the key's slot and take the row's rank inside its key group.  LDS atomics are what bounds this kernel
+    //    (measured with the output stores compiled out: 400 of its 550 us at 2^26 rows), so a row costs two of them,
+    //    not three: a plain read of the slot first (a duplicate of an already published key and every step of a
+    //    collision chain need no ds_cmpst), ds_cmpst only on a slot read as empty, and ONE returning ds_add whose
+    //    old value is the row's rank — the fill then needs no second atomic.
+    unsigned c_slot[kJlCached], c_rid[kJlCached], c_rank[kJlCached];
 #pragma unroll
     for (int r = 0; r < kJlCached; ++r) {
       const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
       c_slot[r] = kJlSubSlots;  // "no row"
       c_rid[r] = 0;
+      c_rank[r] = 0;
       if (i < hi) {
         const u32x2 row = r < kJlPre ? cur[r < kJlPre ? r : 0] : jl_row(pkeys, prids, i);
-        const unsigned key = row.x;
         c_rid[r] = row.y;
-        unsigned s = fmix32(key) & kJlSubMask;
-        unsigned tries = 0;
-        if (key == kEmptyKey) {  // the sentinel is not a key (join/join_omnisci.cpp:52): flag it, drop the row
-          atomicOr(status, DBHIP_DEV_KEY_RANGE);
-          continue;
-        }
-        while (true) {
-          const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
-          if (old == kEmptyKey || old == key) {
-            atomicAdd(&lc[s], 1u);
-            c_slot[r] = s;
-            break;
-          }
-          s = (s + 1) & kJlSubMask;
-          if (++tries > kJlSubMask) {
-            atomicOr(status, DBHIP_DEV_TABLE_FULL);
-            break;
-          }
+        const unsigned s = jl_claim(lk, row.x, status);
+        if (s < kJlSubSlots) {
+          c_slot[r] = s;
+          c_rank[r] = atomicAdd(&lc[s], 1u);
         }
       }
     }
-    for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-      const unsigned key = jl_row(pkeys, prids, i).x;
-      unsigned s = fmix32(key) & kJlSubMask;
-      unsigned tries = 0;
-      if (key == kEmptyKey) {
-        atomicOr(status, DBHIP_DEV_KEY_RANGE);
-        continue;
-      }
-      while (true) {
-        const unsigned old = atomicCAS(&lk[s], kEmptyKey, key);
-        if (old == kEmptyKey || old == key) {
-          atomicAdd(&lc[s], 1u);
-          break;
-        }
-        s = (s + 1) & kJlSubMask;
-        if (++tries > kJlSubMask) {
-          atomicOr(status, DBHIP_DEV_TABLE_FULL);
-          break;
-        }
+    // a partition far above its expected size: the rows beyond the cached ones are counted AFTER every cached row has
+    // its rank (so the cached rows of a key hold the ranks 0 .. k-1 and these rows own the ranks behind them)
+    const bool overflow = hi - lo > static_cast<size_t>(kJlCached) * kJlBuildThreads;  // uniform over the workgroup
+    if (overflow) {
+      JL_BUILD_BARRIER();
+      for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
+        const unsigned s = jl_claim(lk, jl_row(pkeys, prids, i).x, status);
+        if (s < kJlSubSlots) atomicAdd(&lc[s], 1u);
       }
     }
-    __syncthreads();
-    // 2. exclusive scan of the 4096 counts -> first id position of every slot (8 slots per thread)
+    JL_BUILD_BARRIER();
+    // 2. exclusive scan of the counts -> first id position of every slot
     constexpr unsigned kPer = kJlSubSlots / kJlBuildThreads;
     unsigned c[kPer], mine = 0;
 #pragma unroll
@@ -500,36 +512,93 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     }
     const unsigned incl = wave_inclusive_scan(mine);
     if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
+    JL_BUILD_BARRIER();
     unsigned run = static_cast<unsigned>(lo) + incl - mine;
     for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
-    // every thread has its 8 counts in registers (the barrier above): overwrite them with the positions
+    // every thread has its counts in registers (the barrier above): overwrite them with the positions
 #pragma unroll
     for (unsigned j = 0; j < kPer; ++j) {
       lp[tid * kPer + j] = run;
       run += c[j];
     }
-    __syncthreads();
-    // 3. fill: ids[pos[slot]++] = row id — from the registers of step 1, the overflow rows are read again
-#pragma unroll
-    for (int r = 0; r < kJlCached; ++r)
-      if (c_slot[r] < kJlSubSlots) ids[atomicAdd(&lp[c_slot[r]], 1u)] = c_rid[r];
-    for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-      const u32x2 row = jl_row(pkeys, prids, i);
-      const unsigned key = row.x;
-      unsigned s = fmix32(key) & kJlSubMask;
-      for (unsigned tries = 0; tries <= kJlSubMask && lk[s] != key; ++tries) s = (s + 1) & kJlSubMask;
-      if (key != kEmptyKey && lk[s] == key) ids[atomicAdd(&lp[s], 1u)] = row.y;
+    if (tid == kJlBuildThreads - 1) s_end = run;
+    JL_BUILD_BARRIER();
+    // 3. publish the sub-table: {key, first position | count field} for every slot.  Positions are an exclusive scan
+    //    in slot order, so slot i ends where slot i+1 starts (the last one at s_end).  Output stores are what this
+    //    kernel waits for (per-instruction issue cost: with the stores compiled out it ran 150 us shorter at 2^26
+    //    rows), so every store instruction carries 16 bytes per lane: two slots here, four ids below.  Written once,
+    //    read by another launch: non-temporal.
+    u32x4 *dst = reinterpret_cast<u32x4 *>(table + part * kJlSubSlots);  // 16-byte aligned: kJlSubSlots is even
+    const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
+    for (unsigned i = tid; i < kJlSubSlots / 2; i += kJlBuildThreads) {
+      const unsigned p0 = lp[2 * i], p1 = lp[2 * i + 1], p2 = 2 * i + 2 < kJlSubSlots ? lp[2 * i + 2] : s_end;
+      const unsigned c0 = p1 - p0, c1 = p2 - p1;
+      unsigned f0 = c0 ? c0 - 1 : 0u, f1 = c1 ? c1 - 1 : 0u;
+      f0 = f0 < cnt_esc ? f0 : cnt_esc;
+      f1 = f1 < cnt_esc ? f1 : cnt_esc;
+      const unsigned w0 = pos_bits < 32 ? (p0 | (f0 << pos_bits)) : p0, w1 = pos_bits < 32 ? (p1 | (f1 << pos_bits)) : p1;
+#ifndef DBHIP_JL_DBG_NO_PUBLISH
+      __builtin_nontemporal_store(u32x4{lk[2 * i], w0, lk[2 * i + 1], w1}, dst + i);
+#else
+      if (w0 == 0x12345678u && lk[2 * i] == 0x9abcdef0u) dst[i] = u32x4{0u, w1, 0u, 0u};
+#endif
     }
-    __syncthreads();
-    // 4. publish the sub-table: {key, first position} for every slot.  The fill bumped lp[i] to the END of slot
-    //    i's ids, and positions are an exclusive scan in slot order, so slot i starts where slot i-1 ends.
-    u32x2 *dst = table + part * kJlSubSlots;
-    for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads)
-      dst[i] = u32x2{lk[i], i ? lp[i - 1] : static_cast<unsigned>(lo)};
-    if (part + 1 == parts && tid == 0) dst[kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // right neighbour of the last slot
+    if (part + 1 == parts && tid == 0) table[static_cast<size_t>(parts) * kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // sentinel
+    // 4. fill: id position = first position of the slot + rank of the row (slot / rank / row id from the registers of
+    //    step 1: a plain LDS read, no atomic).  The partition's ids are ONE contiguous range [lo, s_end): they are
+    //    staged in LDS — in the key array, free once it is published — and leave as 16-byte stores.  A partition far
+    //    above its expected size (rows beyond the cached ones, `overflow`) stores every id directly instead.
+    unsigned c_pos[kJlCached];
+#pragma unroll
+    for (int r = 0; r < kJlCached; ++r) c_pos[r] = c_slot[r] < kJlSubSlots ? lp[c_slot[r]] + c_rank[r] : 0xFFFFFFFFu;
+    if (!overflow) {
+      JL_BUILD_BARRIER();  // every key and position word has been read: the key array becomes the staging area
+      unsigned *stage = lk;
+      const unsigned lo32 = static_cast<unsigned>(lo);
+#ifndef DBHIP_JL_DBG_NO_IDS
+#pragma unroll
+      for (int r = 0; r < kJlCached; ++r)
+        if (c_pos[r] != 0xFFFFFFFFu) stage[c_pos[r] - lo32] = c_rid[r];  // rows <= cached rows <= kJlSubSlots (static_assert)
+#endif
+      JL_BUILD_BARRIER();
+      const unsigned rows = s_end - lo32;  // counted rows of the partition
+      unsigned *out = ids + lo;
+      const unsigned head0 = ((16u - (static_cast<unsigned>(reinterpret_cast<uintptr_t>(out)) & 15u)) & 15u) / 4u;  // up to the next 16-byte boundary
+      const unsigned head = head0 < rows ? head0 : rows;
+#ifndef DBHIP_JL_DBG_NO_IDS
+      if (tid < head) out[tid] = stage[tid];
+      const unsigned body = (rows - head) / 4;
+      for (unsigned v = tid; v < body; v += kJlBuildThreads) {
+        const unsigned at = head + 4 * v;
+        __builtin_nontemporal_store(u32x4{stage[at], stage[at + 1], stage[at + 2], stage[at + 3]},
+                                    reinterpret_cast<u32x4 *>(out + at));
+      }
+      const unsigned tail0 = head + 4 * body;
+      if (tid < 4 && tail0 + tid < rows) out[tail0 + tid] = stage[tail0 + tid];
+#endif
+    } else {
+#ifndef DBHIP_JL_DBG_NO_IDS
+#pragma unroll
+      for (int r = 0; r < kJlCached; ++r)
+        if (c_pos[r] != 0xFFFFFFFFu) ids[c_pos[r]] = c_rid[r];
+#endif
+      // the uncached rows of a key own the ranks behind its cached rows: they take them from the END of the key's id
+      // range downwards, decrementing a cursor that starts at the next slot's first position (for the last slot:
+      // s_end) — after a barrier: the publish and the cached rows above still needed those words intact
+      JL_BUILD_BARRIER();
+      for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
+        const u32x2 row = jl_row(pkeys, prids, i);
+        const unsigned key = row.x;
+        if (key == kEmptyKey) continue;
+        unsigned s = jl_home_slot(fmix32(key));
+        for (unsigned tries = 0; tries < kJlSubSlots && lk[s] != key; ++tries) s = jl_next_slot(s);
+        if (lk[s] != key) continue;
+        unsigned *cursor = s + 1 < kJlSubSlots ? &lp[s + 1] : &s_end;
+        ids[atomicSub(cursor, 1u) - 1u] = row.y;
+      }
+    }
     if (npart >= parts) break;
-    __syncthreads();  // the LDS arrays and s_wsum are reused by the next partition
+    JL_BUILD_BARRIER();  // the LDS arrays and s_wsum are reused by the next partition
     part = npart;
     lo = nlo;
     hi = nhi;
@@ -538,26 +607,32 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
 
 __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
                                                               const u32x2 *__restrict__ table, unsigned parts,
-                                                              unsigned *__restrict__ out_pos,
+                                                              unsigned pos_bits, unsigned *__restrict__ out_pos,
                                                               unsigned *__restrict__ out_cnt) {
-  // one row per lane per step at full occupancy (32 waves per CU): the probe is pure memory latency,
-  // one random 16-byte gather per row (slot + right neighbour, 8-byte aligned: global_load_dwordx4 needs
-  // no more); unrolling rows per lane measured slower (2.1 vs 1.7 ms at 2^26)
+  // one row per lane per step at full occupancy (32 waves per CU): the probe is pure memory latency, one random
+  // 8-byte gather per row = the slot {key, first position | count field}; the right-hand neighbour is read only
+  // when the field holds the escape value.  (The first layout read slot and neighbour with one 16-byte load at
+  // 8-byte alignment: every eighth row crossed a 64-byte line, i.e. one more memory request; unrolling rows per
+  // lane measured slower, 2.1 vs 1.7 ms at 2^26.)
   const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
+  const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
     const unsigned key = probe[i];
     const unsigned h = fmix32(key);
     const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
-    unsigned s = h & kJlSubMask, pos = 0, cnt = 0;
-    for (unsigned tries = 0; tries <= kJlSubMask && key != kEmptyKey; ++tries) {  // the sentinel never matches
-      const u32x4 e = *reinterpret_cast<const u32x4_a8 *>(sub + s);  // {key, first, next slot's key, next slot's first}
+    unsigned s = jl_home_slot(h), pos = 0, cnt = 0;
+    for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {  // the sentinel never matches
+      const u32x2 e = sub[s];
       if (e.x == key) {
-        pos = e.y;
-        cnt = e.w - e.y;
+        pos = e.y & pos_mask;
+        const unsigned field = pos_bits < 32 ? e.y >> pos_bits : 0u;
+        // s + 1 may be the first slot of the next sub-table (or the sentinel): positions run on across them
+        cnt = field < cnt_esc ? field + 1u : (sub[s + 1].y & pos_mask) - pos;
         break;
       }
       if (e.x == kEmptyKey) break;
-      s = (s + 1) & kJlSubMask;
+      s = jl_next_slot(s);
     }
     out_pos[i] = pos;
     out_cnt[i] = cnt;
@@ -585,7 +660,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
   for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
     const u32x2 row = jl_row(pkeys, prids, i);
     const unsigned key = row.x;
-    unsigned s = fmix32(key) & kJlSubMask;
+    unsigned s = jl_home_slot(fmix32(key));
     if (key == kEmptyKey) {  // the sentinel is not a key: flag it, drop the row
       atomicOr(status, DBHIP_DEV_KEY_RANGE);
       continue;
@@ -597,8 +672,8 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
         break;
       }
       if (old == key) break;
-      s = (s + 1) & kJlSubMask;
-      if (tries >= kJlSubMask) {
+      s = jl_next_slot(s);
+      if (tries + 1 >= kJlSubSlots) {
         atomicOr(status, DBHIP_DEV_TABLE_FULL);
         break;
       }
@@ -606,7 +681,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
   }
   __syncthreads();
   u32x2 *dst = table + part * kJlSubSlots;
-  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) dst[i] = u32x2{lk[i], lv[i]};
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) __builtin_nontemporal_store(u32x2{lk[i], lv[i]}, dst + i);
 }
 
 __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *__restrict__ pkeys,
@@ -620,9 +695,9 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
     const unsigned key = pkeys[i];
     const unsigned h = fmix32(key);
     const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
-    unsigned s = h & kJlSubMask, bval = kEmptyKey;
+    unsigned s = jl_home_slot(h), bval = kEmptyKey;
     bool found = false;
-    for (unsigned tries = 0; tries <= kJlSubMask && key != kEmptyKey; ++tries) {
+    for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {
       const u32x2 e = sub[s];
       if (e.x == key) {
         found = true;
@@ -630,7 +705,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
         break;
       }
       if (e.x == kEmptyKey) break;
-      s = (s + 1) & kJlSubMask;
+      s = jl_next_slot(s);
     }
     // join.cpp:41-43, :96-101: sentinels where the probe row has no partner
     out_key[i] = found ? key : kEmptyKey;
@@ -656,7 +731,7 @@ inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
 
 namespace {
 struct JlPartitioned {
-  const unsigned *keys, *rids;             // partition-major rows: two columns, or rids == nullptr and keys -> pairs
+  const unsigned *keys, *rids;             // partition-major rows: (key, row id) pairs behind `keys`, rids == nullptr
   const unsigned long long *starts;        // parts + 1 offsets
   u32x2 *table;
   unsigned *status;
@@ -666,11 +741,11 @@ struct JlPartitioned {
 int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_t n, void *workspace, hipStream_t s,
                       const DeviceInfo &dev, const JlLayout &L, JlPartitioned *out) {
   char *base = static_cast<char *>(workspace);
-  unsigned *k_a = reinterpret_cast<unsigned *>(base + L.keys_a_off);  // level-0 output: two columns (the level-1
-  unsigned *r_a = reinterpret_cast<unsigned *>(base + L.rids_a_off);  // histogram reads the keys alone)
-  // level-1 output: (key, row id) pairs in the adjacent "keys b" + "row ids b" regions — one 8-byte store per row
-  // makes a run of r rows 8r contiguous bytes instead of two runs of 4r (scatter 330 -> 254 us at 2^26 rows)
-  u32x2 *rows_b = reinterpret_cast<u32x2 *>(base + L.keys_b_off);
+  // both levels write (key, row id) as ONE 8-byte element: a run of r rows is 8r contiguous bytes instead of two
+  // runs of 4r (the scatters are bound by partially written lines: level 1 went 330 -> 254 us at 2^26 rows when it
+  // switched, level 0 followed once the level-1 histogram read pairs instead of a keys-only column)
+  u32x2 *rows_a = reinterpret_cast<u32x2 *>(base + L.keys_a_off);  // level-0 output ("keys a" + "row ids a" regions)
+  u32x2 *rows_b = reinterpret_cast<u32x2 *>(base + L.keys_b_off);  // level-1 output
   unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + L.meta_off);
   // meta: counts0g[G*k1] | cursors0g[G*k1] | starts0[k1+1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
   unsigned long long *counts0 = meta;
@@ -695,19 +770,20 @@ int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
     hipLaunchKernelGGL(jl_scatter0_kernel<false>, dim3(jl_scatter0_grid(tiles, cap)), dim3(kJlThreads),
-                       lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0, k_a, r_a);
+                       lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0,
+                       reinterpret_cast<unsigned *>(rows_a), static_cast<unsigned *>(nullptr));
   }
-  out->keys = k_a;
-  out->rids = r_a;
+  out->keys = reinterpret_cast<const unsigned *>(rows_a);
+  out->rids = nullptr;
   out->starts = starts0;
   if (L.k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
     const size_t lds1 = jl_scatter_lds_bytes(L.k2);
     hipLaunchKernelGGL(jl_hist1_kernel, dim3(L.k1 * kJlHist1WgPerBucket), dim3(kJlThreads), L.k2 * sizeof(unsigned), s,
-                       k_a, starts0, L.parts, L.k2, counts1);
+                       rows_a, starts0, L.parts, L.k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(L.k1), dim3(kJlThreads), 0, s, counts1, starts0, L.k1, L.k2, starts1,
                        cursors1);
-    hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, k_a, r_a, starts0, tstarts0,
+    hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, rows_a, starts0, tstarts0,
                        L.parts, L.k1, L.k2, cursors1, rows_b);
     out->keys = reinterpret_cast<const unsigned *>(rows_b);
     out->rids = nullptr;
@@ -730,10 +806,12 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  const size_t build_cap = static_cast<size_t>(dev.cus) * 4;  // four 512-thread workgroups per CU (32 KiB of LDS each)
+  // as many 512-thread workgroups per CU as their LDS tables allow (48 KiB each at 6144 slots: three)
+  const size_t per_cu = (160 * 1024) / (build_lds + 1024) < 4 ? (160 * 1024) / (build_lds + 1024) : 4;
+  const size_t build_cap = static_cast<size_t>(dev.cus) * (per_cu ? per_cu : 1);
   hipLaunchKernelGGL(jl_build_kernel, dim3(static_cast<unsigned>(L.parts < build_cap ? L.parts : build_cap)),
                      dim3(kJlBuildThreads), build_lds, s, p.keys, p.rids, p.starts,
-                     p.table, L.parts, static_cast<unsigned>(n), ids, p.status);
+                     p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status);
   return launch_status();
 }
 
@@ -764,7 +842,7 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
   const JlLayout L = jl_layout(n_build);
   const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
   hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
-                     table, L.parts, out_pos, out_cnt);
+                     table, L.parts, jl_pos_bits(n_build), out_pos, out_cnt);
   return launch_status();
 }
 
