@@ -1,20 +1,22 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's numbers are judged against (run on the GPU box, from the repo root):
-#   1. --kernel-trace --stats of the bench command itself (per-kernel average durations)
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own passes (HBM traffic per launch)
+#   1. --kernel-trace --stats of the bench command (no selectivity sweep, no CPU legs: every scan dispatch is the headline
+#      configuration or the small result check)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own passes (HBM traffic per launch; MI355X_MICROARCH.md)
 # Raw output goes to gpurun_out/prof_<tag>/; tools/profile_summary.py condenses it into profiles/.
+#   tools/profile_r02.sh <tag> <git head the numbers belong to>
 set -euo pipefail
-tag="${1:-r01}"
+tag="${1:-r02}"; head="${2:-unknown}"
 repo="$(pwd)"
 out="$repo/gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o kt -- python3 "$repo/bench.py" --steps 20 --warmup 3 --no-cpu > "$out/bench_under_kt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o kt -- python3 "$repo/bench.py" --steps 20 --warmup 3 --no-cpu --no-sweep > "$out/bench_under_kt.log" 2>&1
 echo "[profile] kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep > "$out/bench_under_pmc_fetch.log" 2>&1
 echo "[profile] FETCH_SIZE done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep > "$out/bench_under_pmc_write.log" 2>&1
 echo "[profile] WRITE_SIZE done"
 cd "$repo"
-python3 tools/profile_summary.py "$out" "$tag"
+python3 tools/profile_summary.py "$out" "$tag" "$head"
