@@ -537,11 +537,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       f0 = f0 < cnt_esc ? f0 : cnt_esc;
       f1 = f1 < cnt_esc ? f1 : cnt_esc;
       const unsigned w0 = pos_bits < 32 ? (p0 | (f0 << pos_bits)) : p0, w1 = pos_bits < 32 ? (p1 | (f1 << pos_bits)) : p1;
-#ifndef DBHIP_JL_DBG_NO_PUBLISH
       __builtin_nontemporal_store(u32x4{lk[2 * i], w0, lk[2 * i + 1], w1}, dst + i);
-#else
-      if (w0 == 0x12345678u && lk[2 * i] == 0x9abcdef0u) dst[i] = u32x4{0u, w1, 0u, 0u};
-#endif
     }
     if (part + 1 == parts && tid == 0) table[static_cast<size_t>(parts) * kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // sentinel
     // 4. fill: id position = first position of the slot + rank of the row (slot / rank / row id from the registers of
@@ -555,17 +551,14 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       JL_BUILD_BARRIER();  // every key and position word has been read: the key array becomes the staging area
       unsigned *stage = lk;
       const unsigned lo32 = static_cast<unsigned>(lo);
-#ifndef DBHIP_JL_DBG_NO_IDS
 #pragma unroll
       for (int r = 0; r < kJlCached; ++r)
         if (c_pos[r] != 0xFFFFFFFFu) stage[c_pos[r] - lo32] = c_rid[r];  // rows <= cached rows <= kJlSubSlots (static_assert)
-#endif
       JL_BUILD_BARRIER();
       const unsigned rows = s_end - lo32;  // counted rows of the partition
       unsigned *out = ids + lo;
       const unsigned head0 = ((16u - (static_cast<unsigned>(reinterpret_cast<uintptr_t>(out)) & 15u)) & 15u) / 4u;  // up to the next 16-byte boundary
       const unsigned head = head0 < rows ? head0 : rows;
-#ifndef DBHIP_JL_DBG_NO_IDS
       if (tid < head) out[tid] = stage[tid];
       const unsigned body = (rows - head) / 4;
       for (unsigned v = tid; v < body; v += kJlBuildThreads) {
@@ -575,13 +568,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       }
       const unsigned tail0 = head + 4 * body;
       if (tid < 4 && tail0 + tid < rows) out[tail0 + tid] = stage[tail0 + tid];
-#endif
     } else {
-#ifndef DBHIP_JL_DBG_NO_IDS
 #pragma unroll
       for (int r = 0; r < kJlCached; ++r)
         if (c_pos[r] != 0xFFFFFFFFu) ids[c_pos[r]] = c_rid[r];
-#endif
       // the uncached rows of a key own the ranks behind its cached rows: they take them from the END of the key's id
       // range downwards, decrementing a cursor that starts at the next slot's first position (for the last slot:
       // s_end) — after a barrier: the publish and the cached rows above still needed those words intact

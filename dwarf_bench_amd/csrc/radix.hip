@@ -52,7 +52,10 @@ constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wav
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
 constexpr int kRsMaxPasses = 8;
 constexpr int kRsMaxRadix = 256;
-constexpr size_t kRsTargetChunks = 2048;         // chunks per pass (>= 8 per CU for balance)
+#ifndef DBHIP_RS_CHUNKS
+#define DBHIP_RS_CHUNKS 2048
+#endif
+constexpr size_t kRsTargetChunks = DBHIP_RS_CHUNKS;  // chunks per pass (>= 8 per CU for balance)
 constexpr size_t kRsFusedScanChunks = 32;        // up to this many chunks the scatter sums its own prefix (2^16 keys: 89 -> 80 us; at 128 chunks it costs 17 us)
 
 struct RsPass {
@@ -69,6 +72,10 @@ struct RsHeader {
 static_assert(sizeof(RsHeader) == kWsHeader, "workspace header size");
 
 // workspace: header | totals[8][256] | bases[8][256] | counts[radix][chunks]
+// (Measured and dropped for 4-bit digits: per-pass sums of the chunk counts over groups of 64 chunks, added by the
+// histogram workgroups with 16 global atomics each, so that the scatter could find its offsets without a scan kernel —
+// the 2048 workgroups hammer the same 32 cache lines of sums: rs_chunk_hist 12.5 -> 28 us, scatter 31 -> 35 us,
+// 2^24 keys 458 -> 518 us.)
 constexpr size_t kRsTotalsOff = kWsHeader;
 constexpr size_t kRsBasesOff = kRsTotalsOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
 constexpr size_t kRsCountsOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
@@ -121,15 +128,17 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
                                                                   size_t tiles_per_chunk, size_t num_chunks) {
   // One read of the keys: digit totals of EVERY pass and, because the workgroups walk the input chunk by chunk,
   // the per-chunk digit counts of pass 0 as well (counts0[digit][chunk]) — the first pass then needs no
-  // rs_chunk_hist of its own.
+  // rs_chunk_hist of its own.  The LDS histograms are always over BYTES (four ds_add per key): with 4-bit digits the
+  // two nibble histograms of a byte are its row and column sums, taken once per chunk / once at the end — eight
+  // ds_add per key made this kernel 70 us at 2^24 keys against 32 us for the byte version.
+  constexpr int kBins = 256, kBytes = 4;
   constexpr int kRadix = 1 << BITS;
-  constexpr int kPasses = 32 / BITS;
-  __shared__ unsigned s_hist[kPasses * kRadix];  // [0][*] is filled from the chunk counts
-  __shared__ unsigned s_chunk[kRadix];
-  for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) s_hist[i] = 0;
+  __shared__ unsigned s_hist[kBytes * kBins];  // [0][*] is filled from the chunk counts
+  __shared__ unsigned s_chunk[kBins];
+  for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) s_hist[i] = 0;
   const size_t chunk_keys = tiles_per_chunk * kRsTile;
   for (size_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
-    for (int i = threadIdx.x; i < kRadix; i += kRsThreads) s_chunk[i] = 0;
+    for (int i = threadIdx.x; i < kBins; i += kRsThreads) s_chunk[i] = 0;
     __syncthreads();
     const size_t lo = chunk * chunk_keys;
     size_t hi = lo + chunk_keys;
@@ -140,42 +149,55 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
       const u32x4 v = k4[i];
       const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
 #pragma unroll
-      for (int p = 0; p < kPasses; ++p) {
-        unsigned *hist = p == 0 ? s_chunk : s_hist + p * kRadix;
-        // a digit that is the same in the whole wave (the upper bytes of small keys: the reference's
+      for (int p = 0; p < kBytes; ++p) {
+        unsigned *hist = p == 0 ? s_chunk : s_hist + p * kBins;
+        // a byte that is the same in the whole wave (the upper bytes of small keys: the reference's
         // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
-        const unsigned d0 = (k[0] >> (p * BITS)) & (kRadix - 1);
+        const unsigned d0 = (k[0] >> (p * 8)) & (kBins - 1);
         const unsigned first = __builtin_amdgcn_readfirstlane(d0);
-        const bool same = ((k[0] >> (p * BITS)) & (kRadix - 1)) == first && ((k[1] >> (p * BITS)) & (kRadix - 1)) == first &&
-                          ((k[2] >> (p * BITS)) & (kRadix - 1)) == first && ((k[3] >> (p * BITS)) & (kRadix - 1)) == first;
+        const bool same = ((k[0] >> (p * 8)) & (kBins - 1)) == first && ((k[1] >> (p * 8)) & (kBins - 1)) == first &&
+                          ((k[2] >> (p * 8)) & (kBins - 1)) == first && ((k[3] >> (p * 8)) & (kBins - 1)) == first;
         const unsigned long long active = __ballot(true);
         if (__ballot(same) == active) {
           if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
             atomicAdd(&hist[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * BITS)) & (kRadix - 1)], 1u);
+          for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * 8)) & (kBins - 1)], 1u);
         }
       }
     }
     for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
       const unsigned k = keys[i] ^ xor_mask;
-      atomicAdd(&s_chunk[k & (kRadix - 1)], 1u);
+      atomicAdd(&s_chunk[k & (kBins - 1)], 1u);
 #pragma unroll
-      for (int p = 1; p < kPasses; ++p) atomicAdd(&s_hist[p * kRadix + ((k >> (p * BITS)) & (kRadix - 1))], 1u);
+      for (int p = 1; p < kBytes; ++p) atomicAdd(&s_hist[p * kBins + ((k >> (p * 8)) & (kBins - 1))], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
-      const unsigned c = s_chunk[d];
-      counts0[static_cast<size_t>(d) * num_chunks + chunk] = c;
-      s_hist[d] += c;  // thread d owns s_hist[0][d]
+    // pass 0's counts of this chunk: the byte bins themselves, or (4-bit digits) their sums over the high nibble
+    if (BITS == 8) {
+      for (int d = threadIdx.x; d < kRadix; d += kRsThreads) counts0[static_cast<size_t>(d) * num_chunks + chunk] = s_chunk[d];
+    } else if (threadIdx.x < kRadix) {
+      unsigned c = 0;
+#pragma unroll
+      for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunk[hi4 * 16 + threadIdx.x];
+      counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk] = c;
     }
+    for (int d = threadIdx.x; d < kBins; d += kRsThreads) s_hist[d] += s_chunk[d];  // thread d owns s_hist[0][d]
     __syncthreads();
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kPasses * kRadix; i += kRsThreads) {
-    const unsigned c = s_hist[i];
-    if (c) atomicAdd(&totals[(i / kRadix) * kRsMaxRadix + (i % kRadix)], c);
+  if (BITS == 8) {
+    for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) {
+      const unsigned c = s_hist[i];
+      if (c) atomicAdd(&totals[(i / kBins) * kRsMaxRadix + (i % kBins)], c);
+    }
+  } else if (threadIdx.x < kBytes * 2 * kRadix) {  // 8 passes x 16 digits: pass 2q = low nibble of byte q, 2q+1 = high
+    const unsigned pass = threadIdx.x / kRadix, d = threadIdx.x % kRadix, byte = pass / 2;
+    unsigned c = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) c += s_hist[byte * kBins + ((pass & 1u) ? d * 16 + o : o * 16 + d)];
+    if (c) atomicAdd(&totals[pass * kRsMaxRadix + d], c);
   }
 }
 
@@ -252,25 +274,32 @@ template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, const RsHeader *hdr,
                                                                    const unsigned *__restrict__ bases,
                                                                    unsigned *counts, size_t num_chunks) {
+  // one workgroup per digit, ONE sweep: every thread takes `per` consecutive chunk counts (<= 8: at most 4096 chunks),
+  // wave scan of the thread sums, wave sums through LDS (a loop of 512-chunk rounds with three barriers each took 5 us
+  // for 2048 chunks, most of it barrier and LDS latency)
+  constexpr unsigned kMaxPer = 8;
+  static_assert(kRsTargetChunks <= static_cast<size_t>(kMaxPer) * kRsThreads, "chunks per scan workgroup");
   __shared__ unsigned s_wsum[kRsWaves];
-  __shared__ unsigned s_carry;
   if (hdr->pass[pass].skip) return;
   const unsigned d = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned *row = counts + static_cast<size_t>(d) * num_chunks;
-  if (tid == 0) s_carry = bases[pass * kRsMaxRadix + d];
+  const unsigned per = static_cast<unsigned>((num_chunks + kRsThreads - 1) / kRsThreads);
+  const size_t first = static_cast<size_t>(tid) * per;
+  unsigned v[kMaxPer], mine = 0;
+#pragma unroll
+  for (unsigned j = 0; j < kMaxPer; ++j) {
+    v[j] = (j < per && first + j < num_chunks) ? row[first + j] : 0u;
+    mine += v[j];
+  }
+  const unsigned incl = wave_inclusive_scan(mine);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
   __syncthreads();
-  for (size_t base = 0; base < num_chunks; base += kRsThreads) {
-    const size_t i = base + tid;
-    const unsigned v = i < num_chunks ? row[i] : 0u;
-    const unsigned incl = wave_inclusive_scan(v);
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned off = s_carry;
-    for (unsigned w = 0; w < wave; ++w) off += s_wsum[w];
-    if (i < num_chunks) row[i] = off + incl - v;
-    __syncthreads();
-    if (tid == kRsThreads - 1) s_carry = off + incl;
-    __syncthreads();
+  unsigned run = bases[pass * kRsMaxRadix + d] + incl - mine;
+  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+  for (unsigned j = 0; j < kMaxPer; ++j) {
+    if (j < per && first + j < num_chunks) row[first + j] = run;
+    run += v[j];
   }
 }
 

@@ -23,6 +23,7 @@ for bits in (8, 4):
         keys.copy_(keys0); plan.launch(keys)
     run(); run()
     t = ev(run) - ev(lambda: keys.copy_(keys0))
+    run(); torch.cuda.synchronize()
     ok = bool(torch.equal(keys.to(torch.int64) & 0xFFFFFFFF, ref))
     res.append(f"{bits}-bit {t:7.1f} us {'ok' if ok else 'WRONG'}")
 print(f"{os.environ.get('DBHIP_LIB', 'default').split('libdbhip_')[-1]:24s} 2^{lg}: " + "   ".join(res), flush=True)
