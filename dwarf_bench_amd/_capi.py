@@ -34,6 +34,10 @@ SIGNATURES = {
     "dbhip_join_build_u32": (_int, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_build_pairs_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "dbhip_join_probe_u32": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dbhip_join_radix_workspace_bytes": (_sz, [_sz, _sz]),
+    "dbhip_join_radix_partition_u32": (_int, [_int, _vp, _vp, _sz, _sz, _sz, _vp, _sz, _vp]),
+    "dbhip_join_radix_match_u32": (_int, [_sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dbhip_join_radix_u32": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dbhip_join_answers_u32": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "dbhip_ujoin_workspace_bytes": (_sz, [_sz]),
     "dbhip_ujoin_build_u32": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),

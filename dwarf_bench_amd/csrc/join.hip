@@ -147,6 +147,48 @@ extern "C" int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, 
   return join_lds_probe(probe_keys, n_probe, workspace, n_build, out_pos, out_count, as_stream(stream), dev);
 }
 
+// ---- radix join (both sides partitioned alike, fused LDS build + probe): results in the probe side's partition order
+extern "C" size_t dbhip_join_radix_workspace_bytes(size_t n_build, size_t n_probe) {
+  return join_radix_workspace_bytes(n_build, n_probe);
+}
+
+extern "C" int dbhip_join_radix_partition_u32(int probe_side, const uint32_t *keys, const uint32_t *row_ids, size_t n,
+                                              size_t n_build, size_t n_probe, void *workspace, size_t workspace_bytes,
+                                              dbhip_stream_t stream) {
+  if (n != (probe_side ? n_probe : n_build) || (n && !keys)) return DBHIP_EINVAL;
+  if (n_build > kJlMaxRows || n_probe > 0xFFFFFFFFull) return DBHIP_EINVAL;
+  if (!ws_ok(workspace, workspace_bytes, join_radix_workspace_bytes(n_build, n_probe))) return DBHIP_EWORKSPACE;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  return join_radix_partition(probe_side ? 1 : 0, keys, row_ids, n, n_build, n_probe, workspace, as_stream(stream), dev);
+}
+
+extern "C" int dbhip_join_radix_match_u32(size_t n_build, size_t n_probe, uint32_t *ids, uint32_t *out_probe_row_ids,
+                                          uint32_t *out_pos, uint32_t *out_count, void *workspace, size_t workspace_bytes,
+                                          dbhip_stream_t stream) {
+  if ((n_build && !ids) || (n_probe && (!out_probe_row_ids || !out_pos || !out_count))) return DBHIP_EINVAL;
+  if (n_build > kJlMaxRows || n_probe > 0xFFFFFFFFull) return DBHIP_EINVAL;
+  if (!ws_ok(workspace, workspace_bytes, join_radix_workspace_bytes(n_build, n_probe))) return DBHIP_EWORKSPACE;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  return join_radix_match(n_build, n_probe, ids, out_probe_row_ids, out_pos, out_count, workspace, as_stream(stream), dev);
+}
+
+extern "C" int dbhip_join_radix_u32(const uint32_t *build_keys, const uint32_t *build_row_ids, size_t n_build,
+                                    const uint32_t *probe_keys, const uint32_t *probe_row_ids, size_t n_probe, uint32_t *ids,
+                                    uint32_t *out_probe_row_ids, uint32_t *out_pos, uint32_t *out_count, void *workspace,
+                                    size_t workspace_bytes, dbhip_stream_t stream) {
+  int rc = dbhip_join_radix_partition_u32(0, build_keys, build_row_ids, n_build, n_build, n_probe, workspace,
+                                          workspace_bytes, stream);
+  if (rc == 0)
+    rc = dbhip_join_radix_partition_u32(1, probe_keys, probe_row_ids, n_probe, n_build, n_probe, workspace, workspace_bytes,
+                                        stream);
+  if (rc == 0)
+    rc = dbhip_join_radix_match_u32(n_build, n_probe, ids, out_probe_row_ids, out_pos, out_count, workspace,
+                                    workspace_bytes, stream);
+  return rc;
+}
+
 extern "C" size_t dbhip_ujoin_workspace_bytes(size_t n_build) {
   if (jl_use_ujoin(n_build)) return jl_layout(n_build).total;  // radix-partitioned build, LDS sub-tables (join_lds.hip)
   return align_up(kWsHeader + 2 * join_capacity(n_build) * sizeof(unsigned), kWsAlign);

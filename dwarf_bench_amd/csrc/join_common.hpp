@@ -94,6 +94,11 @@ size_t jl_partition_workspace_bytes(unsigned parts);
 int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, unsigned parts, unsigned *out_keys,
                  unsigned *out_rids, unsigned long long *out_counts, void *workspace, hipStream_t s,
                  const DeviceInfo &dev);
+size_t join_radix_workspace_bytes(size_t n_build, size_t n_probe);
+int join_radix_partition(int probe_side, const unsigned *keys, const unsigned *row_ids, size_t n, size_t n_build,
+                         size_t n_probe, void *workspace, hipStream_t s, const DeviceInfo &dev);
+int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *out_rid, unsigned *out_pos, unsigned *out_cnt,
+                     void *workspace, hipStream_t s, const DeviceInfo &dev);
 int jl_route_check(const unsigned *keys, size_t n, unsigned parts, unsigned rank, unsigned long long *result,
                    hipStream_t s, const DeviceInfo &dev);
 int ujoin_lds_build(const unsigned *build_keys, const unsigned *build_vals, size_t n, void *workspace, hipStream_t s,

@@ -417,12 +417,23 @@ __device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigne
 #else
 #define JL_BUILD_BARRIER() wg_barrier_lds_only()
 #endif
+// kMatch = false: the build of the one-to-many join (sub-tables published to HBM for a later probe launch).
+// kMatch = true: the radix join — the probe side was partitioned with the SAME geometry, so partition p of S meets
+// the sub-table of partition p of R while it is still in LDS: no table is written, no random access leaves the CU;
+// results go out in S's partition order together with the probe row ids.
+struct JlMatchArgs {
+  const u32x2 *spairs;               // probe side, partition-major (key, row id) pairs
+  const unsigned long long *sstarts; // parts + 1 offsets
+  unsigned *out_rid, *out_pos, *out_cnt;
+};
+template <bool kMatch>
 __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
                                                                    u32x2 *__restrict__ table, unsigned parts,
                                                                    unsigned n_rows, unsigned pos_bits,
-                                                                   unsigned *__restrict__ ids, unsigned *status) {
+                                                                   unsigned *__restrict__ ids, unsigned *status,
+                                                                   JlMatchArgs match) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
   unsigned *lk = s_lds;                // keys
   unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
@@ -468,12 +479,26 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
         pre[r] = i < nhi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
       }
     }
+    // radix join: this partition's first probe rows (four consecutive ones per lane) are requested now and arrive
+    // while the sub-table is built
+    u32x2 srow[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
+    size_t slo = 0, shi = 0;
+    if (kMatch) {
+      slo = match.sstarts[part];
+      shi = match.sstarts[part + 1];
+      const size_t j0 = slo + 4 * static_cast<size_t>(tid);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j0 + q < shi) srow[q] = match.spairs[j0 + q];
+    }
     JL_BUILD_BARRIER();
     // 1. claim the key's slot and take the row's rank inside its key group.  LDS atomics are what bounds this kernel
     //    (measured with the output stores compiled out: 400 of its 550 us at 2^26 rows), so a row costs two of them,
     //    not three: a plain read of the slot first (a duplicate of an already published key and every step of a
     //    collision chain need no ds_cmpst), ds_cmpst only on a slot read as empty, and ONE returning ds_add whose
-    //    old value is the row's rank — the fill then needs no second atomic.
+    //    old value is the row's rank — the fill then needs no second atomic.  (Advancing all rows of a lane together,
+    //    one probe step per round with their reads and ds_cmpst in flight at once, measured 35 % SLOWER: 1583 vs
+    //    1186 us for the 2^26 build.)
     unsigned c_slot[kJlCached], c_rid[kJlCached], c_rank[kJlCached];
 #pragma unroll
     for (int r = 0; r < kJlCached; ++r) {
@@ -523,6 +548,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     }
     if (tid == kJlBuildThreads - 1) s_end = run;
     JL_BUILD_BARRIER();
+    if (!kMatch) {
     // 3. publish the sub-table: {key, first position | count field} for every slot.  Positions are an exclusive scan
     //    in slot order, so slot i ends where slot i+1 starts (the last one at s_end).  Output stores are what this
     //    kernel waits for (per-instruction issue cost: with the stores compiled out it ran 150 us shorter at 2^26
@@ -540,6 +566,50 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       __builtin_nontemporal_store(u32x4{lk[2 * i], w0, lk[2 * i + 1], w1}, dst + i);
     }
     if (part + 1 == parts && tid == 0) table[static_cast<size_t>(parts) * kJlSubSlots] = u32x2{kEmptyKey, n_rows};  // sentinel
+    } else {
+    // 3'. probe: the rows of S's partition `part` against the sub-table in LDS — plain LDS reads; the results
+    //     {probe row id, first id position, count} leave coalesced in S's partition order
+      //     FOUR consecutive rows per lane: one 16-byte store per output column and lane (4-byte stores made this
+      //     kernel store-issue-bound: 914 us at 2^26 x 2^26 rows)
+      typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+      const size_t jfirst = slo + 4 * static_cast<size_t>(tid);
+      for (size_t j0 = jfirst; j0 < shi; j0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+        unsigned rid[4], pos[4], cnt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rid[q] = pos[q] = cnt[q] = 0;
+          if (j0 + q < shi) {
+            const u32x2 row = j0 == jfirst ? srow[q] : match.spairs[j0 + q];
+            const unsigned key = row.x;
+            rid[q] = row.y;
+            unsigned sl = jl_home_slot(fmix32(key));
+            for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {
+              const unsigned k = lk[sl];
+              if (k == key) {
+                pos[q] = lp[sl];
+                cnt[q] = (sl + 1 < kJlSubSlots ? lp[sl + 1] : s_end) - pos[q];
+                break;
+              }
+              if (k == kEmptyKey) break;
+              sl = jl_next_slot(sl);
+            }
+          }
+        }
+        if (j0 + 3 < shi) {
+          *reinterpret_cast<u32x4_a4 *>(match.out_rid + j0) = u32x4{rid[0], rid[1], rid[2], rid[3]};
+          *reinterpret_cast<u32x4_a4 *>(match.out_pos + j0) = u32x4{pos[0], pos[1], pos[2], pos[3]};
+          *reinterpret_cast<u32x4_a4 *>(match.out_cnt + j0) = u32x4{cnt[0], cnt[1], cnt[2], cnt[3]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (j0 + q < shi) {
+              match.out_rid[j0 + q] = rid[q];
+              match.out_pos[j0 + q] = pos[q];
+              match.out_cnt[j0 + q] = cnt[q];
+            }
+        }
+      }
+    }
     // 4. fill: id position = first position of the slot + rank of the row (slot / rank / row id from the registers of
     //    step 1: a plain LDS read, no atomic).  The partition's ids are ONE contiguous range [lo, s_end): they are
     //    staged in LDS — in the key array, free once it is published — and leave as 16-byte stores.  A partition far
@@ -727,61 +797,81 @@ struct JlPartitioned {
   unsigned *status;
 };
 
-// the one or two scatter levels shared by both joins: fills `out` and returns a HIP/dbhip status
-int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_t n, void *workspace, hipStream_t s,
-                      const DeviceInfo &dev, const JlLayout &L, JlPartitioned *out) {
-  char *base = static_cast<char *>(workspace);
+// The one or two scatter levels shared by all joins, for a column of n rows and a partition geometry that may come
+// from ANOTHER column (the radix join partitions the probe side by the build side's geometry): level-0 output in
+// rows_a, level-1 output (k2 > 1) in rows_b, offsets in `meta` (jl_meta_bytes(k1, parts) bytes).
+int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, unsigned parts, unsigned k1, unsigned k2,
+                      unsigned log2_k2, u32x2 *rows_a, u32x2 *rows_b, unsigned long long *meta, size_t meta_bytes,
+                      hipStream_t s, const DeviceInfo &dev, const unsigned **out_pairs,
+                      const unsigned long long **out_starts) {
+  // meta: counts0g[G*k1] | cursors0g[G*k1] | starts0[k1+1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
+  unsigned long long *counts0 = meta;
+  unsigned long long *cursors0 = counts0 + static_cast<size_t>(kJlGroups) * k1;
+  unsigned long long *starts0 = cursors0 + static_cast<size_t>(kJlGroups) * k1;
+  unsigned long long *tstarts0 = starts0 + k1 + 1;
+  unsigned long long *counts1 = tstarts0 + k1 + 1;
+  unsigned long long *starts1 = counts1 + parts;
+  unsigned long long *cursors1 = starts1 + parts + 1;
+
+  const hipError_t e = fill_async(meta, 0, meta_bytes, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+
   // both levels write (key, row id) as ONE 8-byte element: a run of r rows is 8r contiguous bytes instead of two
   // runs of 4r (the scatters are bound by partially written lines: level 1 went 330 -> 254 us at 2^26 rows when it
   // switched, level 0 followed once the level-1 histogram read pairs instead of a keys-only column)
-  u32x2 *rows_a = reinterpret_cast<u32x2 *>(base + L.keys_a_off);  // level-0 output ("keys a" + "row ids a" regions)
-  u32x2 *rows_b = reinterpret_cast<u32x2 *>(base + L.keys_b_off);  // level-1 output
-  unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + L.meta_off);
-  // meta: counts0g[G*k1] | cursors0g[G*k1] | starts0[k1+1] | tile_starts0[k1+1] | counts1[K] | starts1[K+1] | cursors1[K]
-  unsigned long long *counts0 = meta;
-  unsigned long long *cursors0 = counts0 + static_cast<size_t>(kJlGroups) * L.k1;
-  unsigned long long *starts0 = cursors0 + static_cast<size_t>(kJlGroups) * L.k1;
-  unsigned long long *tstarts0 = starts0 + L.k1 + 1;
-  unsigned long long *counts1 = tstarts0 + L.k1 + 1;
-  unsigned long long *starts1 = counts1 + L.parts;
-  unsigned long long *cursors1 = starts1 + L.parts + 1;
-
-  hipError_t e = fill_async(base, 0, kWsHeader, s);
-  if (e == hipSuccess) e = fill_async(meta, 0, L.meta_bytes, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-
-  const unsigned k2_shift = L.log2_k2;
-  const size_t lds0 = jl_scatter_lds_bytes(L.k1);
+  const unsigned k2_shift = log2_k2;
+  const size_t lds0 = jl_scatter_lds_bytes(k1);
   hipLaunchKernelGGL(jl_hist0_kernel<false>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
-                     L.k1 * sizeof(unsigned), s, build_keys, n, L.parts, k2_shift, L.k1, counts0);
-  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, L.k1, cursors0, starts0, tstarts0,
+                     k1 * sizeof(unsigned), s, keys, n, parts, k2_shift, k1, counts0);
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, cursors0, starts0, tstarts0,
                      static_cast<unsigned long long *>(nullptr));
   {
     const size_t tiles = (n + kJlTile - 1) / kJlTile;
     const size_t cap = static_cast<size_t>(dev.cus) * 8;
     hipLaunchKernelGGL(jl_scatter0_kernel<false>, dim3(jl_scatter0_grid(tiles, cap)), dim3(kJlThreads),
-                       lds0, s, build_keys, row_ids, 0ull, n, L.parts, k2_shift, L.k1, cursors0,
+                       lds0, s, keys, row_ids, 0ull, n, parts, k2_shift, k1, cursors0,
                        reinterpret_cast<unsigned *>(rows_a), static_cast<unsigned *>(nullptr));
   }
-  out->keys = reinterpret_cast<const unsigned *>(rows_a);
-  out->rids = nullptr;
-  out->starts = starts0;
-  if (L.k2 > 1) {
-    const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + L.k1);
-    const size_t lds1 = jl_scatter_lds_bytes(L.k2);
-    hipLaunchKernelGGL(jl_hist1_kernel, dim3(L.k1 * kJlHist1WgPerBucket), dim3(kJlThreads), L.k2 * sizeof(unsigned), s,
-                       rows_a, starts0, L.parts, L.k2, counts1);
-    hipLaunchKernelGGL(jl_offsets1_kernel, dim3(L.k1), dim3(kJlThreads), 0, s, counts1, starts0, L.k1, L.k2, starts1,
+  *out_pairs = reinterpret_cast<const unsigned *>(rows_a);
+  *out_starts = starts0;
+  if (k2 > 1) {
+    const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + k1);
+    const size_t lds1 = jl_scatter_lds_bytes(k2);
+    hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
+                       rows_a, starts0, parts, k2, counts1);
+    hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,
                        cursors1);
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, rows_a, starts0, tstarts0,
-                       L.parts, L.k1, L.k2, cursors1, rows_b);
-    out->keys = reinterpret_cast<const unsigned *>(rows_b);
-    out->rids = nullptr;
-    out->starts = starts1;
+                       parts, k1, k2, cursors1, rows_b);
+    *out_pairs = reinterpret_cast<const unsigned *>(rows_b);
+    *out_starts = starts1;
   }
+  return launch_status();
+}
+
+// the build side of the one-to-many / unique-key joins, laid out by jl_layout(n): fills `out`
+int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_t n, void *workspace, hipStream_t s,
+                      const DeviceInfo &dev, const JlLayout &L, JlPartitioned *out) {
+  char *base = static_cast<char *>(workspace);
+  const hipError_t e = fill_async(base, 0, kWsHeader, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  out->rids = nullptr;
   out->table = reinterpret_cast<u32x2 *>(base + L.table_off);
   out->status = reinterpret_cast<unsigned *>(base);
-  return launch_status();
+  return jl_partition_side(build_keys, row_ids, n, L.parts, L.k1, L.k2, L.log2_k2,
+                           reinterpret_cast<u32x2 *>(base + L.keys_a_off), reinterpret_cast<u32x2 *>(base + L.keys_b_off),
+                           reinterpret_cast<unsigned long long *>(base + L.meta_off), L.meta_bytes, s, dev, &out->keys,
+                           &out->starts);
+}
+
+size_t jl_build_lds_bytes() { return 2 * static_cast<size_t>(kJlSubSlots) * sizeof(unsigned); }
+unsigned jl_build_grid(unsigned parts, const DeviceInfo &dev) {
+  // as many 512-thread workgroups per CU as their LDS tables allow (24 KiB each at 3072 slots: four)
+  const size_t lds = jl_build_lds_bytes();
+  const size_t by_lds = (160 * 1024) / (lds + 1024), by_threads = 2048 / kJlBuildThreads;
+  const size_t per_cu = by_lds < by_threads ? by_lds : by_threads;
+  const size_t cap = static_cast<size_t>(dev.cus) * (per_cu ? per_cu : 1);
+  return static_cast<unsigned>(parts < cap ? parts : cap);
 }
 }  // namespace
 
@@ -792,16 +882,85 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   JlPartitioned p;
   const int rc = jl_partition_rows(build_keys, row_ids, n, workspace, s, dev, L, &p);
   if (rc != 0) return rc;
-  const size_t build_lds = 2 * kJlSubSlots * sizeof(unsigned);
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel),
+  const size_t build_lds = jl_build_lds_bytes();
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  // as many 512-thread workgroups per CU as their LDS tables allow (48 KiB each at 6144 slots: three)
-  const size_t per_cu = (160 * 1024) / (build_lds + 1024) < 4 ? (160 * 1024) / (build_lds + 1024) : 4;
-  const size_t build_cap = static_cast<size_t>(dev.cus) * (per_cu ? per_cu : 1);
-  hipLaunchKernelGGL(jl_build_kernel, dim3(static_cast<unsigned>(L.parts < build_cap ? L.parts : build_cap)),
-                     dim3(kJlBuildThreads), build_lds, s, p.keys, p.rids, p.starts,
-                     p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status);
+  hipLaunchKernelGGL(jl_build_kernel<false>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, p.keys,
+                     p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
+                     JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr});
+  return launch_status();
+}
+
+// ---- radix join: both sides partitioned with the build side's geometry, one fused build + probe launch -----------
+// workspace: header | build side: pairs a, pairs b, meta | probe side: pairs a, pairs b, meta
+namespace {
+struct JrLayout {
+  unsigned parts, k1, k2, log2_k2;
+  size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, total;
+};
+JrLayout jr_layout(size_t n_build, size_t n_probe) {
+  const JlLayout G = jl_layout(n_build);
+  JrLayout L;
+  L.parts = G.parts; L.k1 = G.k1; L.k2 = G.k2; L.log2_k2 = G.log2_k2;
+  L.meta_bytes = G.meta_bytes;
+  const size_t cb = align_up((n_build ? n_build : 1) * 8, kWsAlign), cp = align_up((n_probe ? n_probe : 1) * 8, kWsAlign);
+  const size_t mb = align_up(L.meta_bytes, kWsAlign);
+  L.b_a = kWsHeader;
+  L.b_b = L.b_a + cb;
+  L.b_meta = L.b_b + (L.k2 > 1 ? cb : 0);
+  L.p_a = L.b_meta + mb;
+  L.p_b = L.p_a + cp;
+  L.p_meta = L.p_b + (L.k2 > 1 ? cp : 0);
+  L.total = L.p_meta + mb;
+  return L;
+}
+// where a partitioned side ended up is a pure function of the sizes: no state is kept between the calls
+void jr_side(const JrLayout &L, char *base, bool probe, const unsigned **pairs, const unsigned long long **starts) {
+  const size_t a = probe ? L.p_a : L.b_a, b = probe ? L.p_b : L.b_b, m = probe ? L.p_meta : L.b_meta;
+  unsigned long long *meta = reinterpret_cast<unsigned long long *>(base + m);
+  unsigned long long *starts0 = meta + 2 * static_cast<size_t>(kJlGroups) * L.k1;
+  unsigned long long *starts1 = starts0 + 2 * (static_cast<size_t>(L.k1) + 1) + L.parts;
+  *pairs = reinterpret_cast<const unsigned *>(base + (L.k2 > 1 ? b : a));
+  *starts = L.k2 > 1 ? starts1 : starts0;
+}
+}  // namespace
+
+size_t join_radix_workspace_bytes(size_t n_build, size_t n_probe) { return jr_layout(n_build, n_probe).total; }
+
+int join_radix_partition(int probe_side, const unsigned *keys, const unsigned *row_ids, size_t n, size_t n_build,
+                         size_t n_probe, void *workspace, hipStream_t s, const DeviceInfo &dev) {
+  const JrLayout L = jr_layout(n_build, n_probe);
+  char *base = static_cast<char *>(workspace);
+  if (!probe_side) {  // the build side's call opens a join: it clears the status word
+    const hipError_t e = fill_async(base, 0, kWsHeader, s);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  const unsigned *pairs;
+  const unsigned long long *starts;
+  return jl_partition_side(keys, row_ids, n, L.parts, L.k1, L.k2, L.log2_k2,
+                           reinterpret_cast<u32x2 *>(base + (probe_side ? L.p_a : L.b_a)),
+                           reinterpret_cast<u32x2 *>(base + (probe_side ? L.p_b : L.b_b)),
+                           reinterpret_cast<unsigned long long *>(base + (probe_side ? L.p_meta : L.b_meta)), L.meta_bytes, s,
+                           dev, &pairs, &starts);
+}
+
+int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *out_rid, unsigned *out_pos, unsigned *out_cnt,
+                     void *workspace, hipStream_t s, const DeviceInfo &dev) {
+  const JrLayout L = jr_layout(n_build, n_probe);
+  char *base = static_cast<char *>(workspace);
+  const unsigned *bp, *pp;
+  const unsigned long long *bs, *ps;
+  jr_side(L, base, false, &bp, &bs);
+  jr_side(L, base, true, &pp, &ps);
+  const size_t build_lds = jl_build_lds_bytes();
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
+                     static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
+                     static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, reinterpret_cast<unsigned *>(base),
+                     JlMatchArgs{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt});
   return launch_status();
 }
 

@@ -205,9 +205,22 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
 #pragma unroll
   for (int w = 0; w < 256 / kWave; ++w) prefix += s_part[w];
   const unsigned m = counts[chunk];
-  const int *src = staging + chunk * chunk_elems;
+  const int *src = staging + chunk * chunk_elems;  // 16-byte aligned: chunk_elems is a multiple of the tile
   int *dst = out + prefix;
-  for (unsigned j = tid; j < m; j += 256) dst[j] = src[j];
+  // 16 bytes per lane: the destination decides the alignment (elements up to its next 16-byte boundary go one by
+  // one), the source is then read at whatever alignment that leaves (4-byte aligned 16-byte loads are legal on
+  // global memory); at dense selectivities this kernel moves as many bytes as the stream itself
+  const unsigned head0 = ((16u - (static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst)) & 15u)) & 15u) / 4u;
+  const unsigned head = head0 < m ? head0 : m;
+  if (tid < head) dst[tid] = src[tid];
+  const unsigned body = (m - head) / 4;
+  typedef int i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  for (unsigned v = tid; v < body; v += 256) {
+    const i32x4 x = *reinterpret_cast<const i32x4_a4 *>(src + head + 4 * v);
+    __builtin_nontemporal_store(x, reinterpret_cast<i32x4 *>(dst + head + 4 * v));
+  }
+  const unsigned tail0 = head + 4 * body;
+  if (tid < 4 && tail0 + tid < m) dst[tail0 + tid] = src[tail0 + tid];
   if (chunk == num_chunks - 1 && tid == 0) {
     *out_size = prefix + m;
     ws->status = DBHIP_DEV_OK;  // nothing on this path can fail on the device; the header is not cleared up front

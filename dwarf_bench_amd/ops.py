@@ -222,6 +222,54 @@ class HashJoin:
         return self.pos[: self.np], self.cnt[: self.np], self.ids[: self.nb]
 
 
+class RadixJoin:
+    """dwarf 4a without the probe-row-order guarantee: both sides partitioned alike, one fused LDS build + probe launch.
+    Results: probe_row_ids / pos / cnt in the probe side's partition order + the id buffer (dbhip_join_radix_*)."""
+
+    def __init__(self, n_build: int, n_probe: int, device="cuda"):
+        self.nb, self.np = n_build, n_probe
+        self.ws_bytes = _capi.lib().dbhip_join_radix_workspace_bytes(n_build, n_probe)
+        self.ws = _ws(self.ws_bytes, device)
+        self.ids = torch.empty(max(n_build, 1), dtype=torch.int32, device=device)
+        self.rid = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+        self.pos = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+        self.cnt = torch.empty(max(n_probe, 1), dtype=torch.int32, device=device)
+
+    def _partition(self, side: int, keys: torch.Tensor, row_ids: torch.Tensor | None) -> None:
+        _need(keys, torch.int32, "keys")
+        if row_ids is not None:
+            _need(row_ids, torch.int32, "row_ids")
+        _capi.check(_capi.lib().dbhip_join_radix_partition_u32(side, keys.data_ptr(),
+                                                               row_ids.data_ptr() if row_ids is not None else None,
+                                                               keys.numel(), self.nb, self.np, self.ws.data_ptr(),
+                                                               self.ws_bytes, _stream()), "join_radix_partition_u32")
+
+    def partition_build(self, keys: torch.Tensor, row_ids: torch.Tensor | None = None) -> None:
+        self._partition(0, keys, row_ids)
+
+    def partition_probe(self, keys: torch.Tensor, row_ids: torch.Tensor | None = None) -> None:
+        self._partition(1, keys, row_ids)
+
+    def match(self) -> None:
+        _capi.check(_capi.lib().dbhip_join_radix_match_u32(self.nb, self.np, self.ids.data_ptr(), self.rid.data_ptr(),
+                                                           self.pos.data_ptr(), self.cnt.data_ptr(), self.ws.data_ptr(),
+                                                           self.ws_bytes, _stream()), "join_radix_match_u32")
+
+    def result(self):
+        """-> probe_row_ids, pos, cnt (probe partition order), ids"""
+        _check_status(self.ws, "join_radix")
+        return self.rid[: self.np], self.pos[: self.np], self.cnt[: self.np], self.ids[: self.nb]
+
+
+def radix_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None,
+               probe_row_ids: torch.Tensor | None = None):
+    plan = RadixJoin(build_keys.numel(), probe_keys.numel(), build_keys.device)
+    plan.partition_build(build_keys, build_row_ids)
+    plan.partition_probe(probe_keys, probe_row_ids)
+    plan.match()
+    return plan.result()
+
+
 def join_answers(ids: torch.Tensor, pos: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
     """(n_probe, 2) int64: the reference's JoinOneToMany records {device pointer into ids, size}
     (common/dpcpp/omnisci_hashtable.hpp:12-17)"""

@@ -141,6 +141,27 @@ int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void 
                          size_t n_build, uint32_t *out_pos, uint32_t *out_count,
                          dbhip_stream_t stream);
 
+/* ---- dwarf 4a, radix join: the same one-to-many join for callers that do not need the results in probe-row order
+ * (the multi-GPU join, whose results stay sharded anyway).  Both sides are partitioned with the BUILD side's geometry
+ * (a pure function of n_build), then ONE launch builds every partition's sub-table in LDS and probes it with the
+ * probe rows of the same partition while it is still there: no table in HBM, no random access leaves a CU.
+ * Outputs: ids[] grouped by key as above; out_probe_row_ids / out_pos / out_count hold, in the probe side's PARTITION
+ * order, each probe row's id (probe_row_ids[i], or i when probe_row_ids is NULL), the offset of its ids and their
+ * number.  The three steps are separate entry points so that a host can overlap them with other work (the build
+ * side's partition call opens a join: it clears the status word and must come first); dbhip_join_radix_u32 runs all
+ * three.  Same contract violations as above (sentinel key, more than 3072 distinct keys in one partition).     */
+size_t dbhip_join_radix_workspace_bytes(size_t n_build, size_t n_probe);
+int dbhip_join_radix_partition_u32(int probe_side, const uint32_t *keys, const uint32_t *row_ids, size_t n,
+                                   size_t n_build, size_t n_probe, void *workspace, size_t workspace_bytes,
+                                   dbhip_stream_t stream);
+int dbhip_join_radix_match_u32(size_t n_build, size_t n_probe, uint32_t *ids, uint32_t *out_probe_row_ids,
+                               uint32_t *out_pos, uint32_t *out_count, void *workspace, size_t workspace_bytes,
+                               dbhip_stream_t stream);
+int dbhip_join_radix_u32(const uint32_t *build_keys, const uint32_t *build_row_ids, size_t n_build,
+                         const uint32_t *probe_keys, const uint32_t *probe_row_ids, size_t n_probe, uint32_t *ids,
+                         uint32_t *out_probe_row_ids, uint32_t *out_pos, uint32_t *out_count, void *workspace,
+                         size_t workspace_bytes, dbhip_stream_t stream);
+
 /* The reference's answer record (JoinOneToMany<global_ptr<size_t>>, common/dpcpp/omnisci_hashtable.hpp:12-17: pointer
  * into the id buffer + number of ids) for callers that want that shape instead of two 32-bit columns:
  * answers[i] = {ids + out_pos[i], out_count[i]} (a miss: {ids, 0}).  16 bytes per probe row.          */

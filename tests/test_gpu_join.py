@@ -188,3 +188,45 @@ def test_join_answers_records():
     ans = ops.join_answers(ids, pos, cnt).cpu().numpy()
     assert np.array_equal(ans[:, 1], cnt.cpu().numpy().astype(np.int64))
     assert np.array_equal(ans[:, 0], ids.data_ptr() + 4 * pos.cpu().numpy().astype(np.int64))
+
+
+# ---- radix join (dbhip_join_radix_*): same semantics, results in the probe side's partition order -------------------
+@pytest.mark.parametrize("nb,npr,hi", [(0, 10, 5), (10, 0, 5), (1, 1, 1), (1000, 777, 300), (4096, 4096, 10000),
+                                       (100003, 65537, 5000), (1 << 17, 1 << 17, (1 << 17) - 1), (300007, 1 << 18, 2**32 - 2),
+                                       (1 << 20, 1 << 19, 10000)])
+def test_radix_join_matches_oracle(nb, npr, hi):
+    """per probe row (found through its row id): count == the key's multiplicity, ids = exactly the build rows with
+    the key (join/join_omnisci.cpp:31-45); every probe row appears once; ids are a permutation of the build rows"""
+    from dwarf_bench_amd import ops
+    a = ops.gen_uniform_u32(nb, 42, 0 if hi == 2**32 - 2 else 1, hi)
+    b = ops.gen_uniform_u32(npr, 43, 0 if hi == 2**32 - 2 else 1, hi)
+    rid, pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.radix_join(a, b))
+    ha, hb = a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.sort(rid), np.arange(npr, dtype=np.uint32))
+    assert np.array_equal(np.sort(ids), np.arange(nb, dtype=np.uint32))
+    want = po.join_counts_fast(ha, hb).astype(np.uint32) if nb and npr else np.zeros(npr, dtype=np.uint32)
+    assert np.array_equal(cnt, want[rid])
+    hit = cnt > 0
+    assert np.all(ha[ids[pos[hit]]] == hb[rid[hit]]) and np.all(ha[ids[pos[hit] + cnt[hit] - 1]] == hb[rid[hit]])
+    if nb <= 4096 and nb and npr:  # every id of every row
+        bc, off, bids = po.join_bruteforce(ha, hb)
+        for i in range(0, npr, 7):
+            r = int(rid[i])
+            assert np.array_equal(np.sort(ids[pos[i]: pos[i] + cnt[i]]).astype(np.uint64), bids[int(off[r]): int(off[r + 1])])
+
+
+def test_radix_join_carries_caller_row_ids_and_agrees_with_the_probe_path():
+    from dwarf_bench_amd import ops
+    n, first = 1 << 18, 3 << 20
+    a = ops.gen_uniform_u32(n, 42, 0, n - 1, first_index=first)
+    b = ops.gen_uniform_u32(n + 5, 43, 0, n - 1, first_index=first)
+    ar = torch.arange(first, first + n, device="cuda", dtype=torch.int64).to(torch.int32)
+    br = torch.arange(first, first + n + 5, device="cuda", dtype=torch.int64).to(torch.int32)
+    rid, pos, cnt, ids = ops.radix_join(a, b, ar, br)
+    srt = a.clone()
+    ops.radix_sort_(srt)
+    # the device-side validator regenerates the key of every global id
+    assert ops.check_gen_uniform(b[(rid.to(torch.int64) - first)], 43, 0, n - 1, indices=rid) == 0
+    assert ops.check_join(srt, b[(rid.to(torch.int64) - first)].contiguous(), pos, cnt, ids, build_keys=None, gen=(42, 0, n - 1))[0] == 0
+    p2, c2, _ = ops.hash_join(a, b)
+    assert torch.equal(c2[(rid.to(torch.int64) - first)], cnt)
