@@ -20,6 +20,7 @@ SIGNATURES = {
     "dbhip_device_info": (_int, [_int, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_int)]),
     "dbhip_workspace_status": (_int, [_vp, C.POINTER(_u32), _vp]),
     "dbhip_gen_uniform_u32": (_int, [_vp, _sz, _u64, _u64, _u32, _u32, _vp]),
+    "dbhip_gen_uniform_at_u32": (_int, [_vp, _vp, _sz, _u64, _u32, _u32, _vp]),
     "dbhip_gen_unique_sorted_u32": (_int, [_vp, _sz, _u64, _u64, _vp]),
     "dbhip_copy_if_lt_i32_workspace_bytes": (_sz, [_sz]),
     "dbhip_copy_if_lt_i32": (_int, [_vp, _sz, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -55,6 +55,13 @@ __global__ __launch_bounds__(kGenThreads) void gen_uniform_u32_kernel(uint32_t *
     out[i] = lo + static_cast<uint32_t>(mix64(seed, first + i) % span);
 }
 
+__global__ __launch_bounds__(kGenThreads) void gen_uniform_at_u32_kernel(uint32_t *out, const uint32_t *__restrict__ indices,
+                                                                          size_t n, uint64_t seed, uint32_t lo, uint64_t span) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kGenThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kGenThreads + threadIdx.x; i < n; i += stride)
+    out[i] = lo + static_cast<uint32_t>(mix64(seed, indices[i]) % span);
+}
+
 __global__ __launch_bounds__(kGenThreads) void gen_unique_sorted_u32_kernel(uint32_t *out, size_t n,
                                                                              uint64_t seed,
                                                                              uint64_t first) {
@@ -126,6 +133,16 @@ extern "C" int dbhip_gen_uniform_u32(uint32_t *out, size_t n, uint64_t seed, uin
   const uint64_t span = static_cast<uint64_t>(hi) - lo + 1;
   hipLaunchKernelGGL(gen_uniform_u32_kernel, dim3(gen_grid(n)), dim3(kGenThreads), 0,
                      as_stream(stream), out, n, seed, first_index, lo, span);
+  return launch_status();
+}
+
+extern "C" int dbhip_gen_uniform_at_u32(uint32_t *out, const uint32_t *indices, size_t n, uint64_t seed, uint32_t lo,
+                                        uint32_t hi, dbhip_stream_t stream) {
+  if (n == 0) return DBHIP_OK;
+  if (!out || !indices || hi < lo) return DBHIP_EINVAL;
+  const uint64_t span = static_cast<uint64_t>(hi) - lo + 1;
+  hipLaunchKernelGGL(gen_uniform_at_u32_kernel, dim3(gen_grid(n)), dim3(kGenThreads), 0, as_stream(stream), out, indices, n,
+                     seed, lo, span);
   return launch_status();
 }
 

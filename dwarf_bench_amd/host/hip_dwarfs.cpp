@@ -896,6 +896,8 @@ void NestedLoopJoinHip::init(const RunOptions &opts) { common_init(*this, opts);
 // Ranks on distinct GPUs exchange through ONE RCCL group of ncclSend/ncclRecv per relation; more ranks than GPUs
 // (rehearsal on one GPU; DWARF_BENCH_PJOIN_EXCHANGE=copy forces it) share devices and push with hipMemcpyPeerAsync.
 // DWARF_BENCH_PJOIN_DIRECT=1 with --gpus 1: the plain local join (the P = 1 point of a scaling curve).
+// The local join of every rank is the radix join (dbhip_join_radix_*: received pairs partitioned once more, fused LDS
+// build + probe, no table in HBM); DWARF_BENCH_PJOIN_LOCAL=probe selects build + row-ordered probe instead.
 // HashJoinResult: build_time = start -> every rank's build done, probe_time = the rest; the phase lines printed per
 // iteration are device-event spans (max over ranks) and overlap by design.
 // Checks, every iteration and at every size, on the device: the exchange conserves the four columns (wrap-around
@@ -914,6 +916,8 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
   const char *force = std::getenv("DWARF_BENCH_PJOIN_EXCHANGE");
   po.force_copy = force && std::string(force) == "copy";
   po.direct_single = env_flag("DWARF_BENCH_PJOIN_DIRECT");
+  const char *local = std::getenv("DWARF_BENCH_PJOIN_LOCAL");  // "probe": build + row-ordered probe instead of the radix join
+  po.radix_local = !(local && std::string(local) == "probe");
   int ndev = 0;
   hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
   pjoin::Engine engine(n, po);

@@ -80,6 +80,7 @@ struct Rank {
   size_t part_ws_bytes = 0;
   DevMem rk, rr, sk, sr;            // received pairs
   DevMem join_ws, ids, pos, cnt;
+  DevMem out_rid;                   // radix local join: probe row ids in result order (results are not in received order)
   size_t recv_r = 0, recv_s = 0;
   DevMem chk;                       // validator results / conservation sums
   ncclComm_t comm = nullptr;
@@ -168,16 +169,26 @@ struct Engine::Impl {
         rids.reserve(k->device, total * 4 + total / 16 * 4);
       }
       if (rel == 0) {
-        const size_t need = dbhip_join_workspace_bytes(total);
+        // radix join: the build side's regions of the workspace depend on the build size alone; the probe side's size is
+        // only known after S's counts, so the workspace is re-checked then (rel == 1)
+        const size_t need = opt.radix_local ? dbhip_join_radix_workspace_bytes(total, k->recv_s) : dbhip_join_workspace_bytes(total);
         if (need > k->join_ws.bytes || total * 4 > k->ids.bytes) {
           sync_all();
           k->join_ws.reserve(k->device, need + need / 16);
           k->ids.reserve(k->device, total * 4 + total / 16 * 4);
         }
-      } else if (total * 4 > k->pos.bytes) {
-        sync_all();
-        k->pos.reserve(k->device, total * 4 + total / 16 * 4);
-        k->cnt.reserve(k->device, total * 4 + total / 16 * 4);
+      } else {
+        if (total * 4 > k->pos.bytes) {
+          sync_all();
+          k->pos.reserve(k->device, total * 4 + total / 16 * 4);
+          k->cnt.reserve(k->device, total * 4 + total / 16 * 4);
+          k->out_rid.reserve(k->device, total * 4 + total / 16 * 4);
+        }
+        if (opt.radix_local && dbhip_join_radix_workspace_bytes(k->recv_r, total) > k->join_ws.bytes) {
+          // (steady state never gets here: plan() sized the workspace for both sides; growing it would lose the
+          //  build side already partitioned into it, so this is a hard error rather than a silent re-run)
+          fail("partitioned join: receive sizes changed between the planning pass and a step");
+        }
       }
     }
   }
@@ -343,10 +354,12 @@ void Engine::plan() {
   if (m.direct) {
     Rank &k = m.local(0);
     k.recv_r = k.recv_s = k.n_local;
-    k.join_ws.reserve(k.device, dbhip_join_workspace_bytes(k.n_local));
+    k.join_ws.reserve(k.device, m.opt.radix_local ? dbhip_join_radix_workspace_bytes(k.n_local, k.n_local)
+                                                   : dbhip_join_workspace_bytes(k.n_local));
     k.ids.reserve(k.device, k.n_local * 4);
     k.pos.reserve(k.device, k.n_local * 4);
     k.cnt.reserve(k.device, k.n_local * 4);
+    k.out_rid.reserve(k.device, k.n_local * 4);
     m.planned = true;
     return;
   }
@@ -362,6 +375,11 @@ void Engine::plan() {
   m.gather_counts(0);
   m.gather_counts(1);
   m.sync_all();
+  for (auto &k : m.ranks) {  // both receive sizes at once: the radix join's workspace depends on both
+    k->recv_s = 0;
+    for (unsigned q = 0; q < m.P; ++q) k->recv_s += Impl::cell(*k, m.P, 1, q, k->id);
+    k->recv_s += k->recv_s / 16;  // the headroom the buffers get
+  }
   m.size_receives(0);
   m.size_receives(1);
   m.planned = true;
@@ -376,12 +394,23 @@ StepTimes Engine::step() {
     Rank &k = m.local(0);
     m.set(k);
     hip_ok(hipEventRecord(k.ev_start, k.compute), "hipEventRecord");
-    db_ok(dbhip_join_build_u32(k.build.as<uint32_t>(), k.n_local, k.ids.as<uint32_t>(), k.join_ws.p, k.join_ws.bytes, k.compute),
-          "dbhip_join_build_u32");
-    hip_ok(hipEventRecord(k.ev_build, k.compute), "hipEventRecord");
-    db_ok(dbhip_join_probe_u32(k.probe.as<uint32_t>(), k.n_local, k.join_ws.p, k.n_local, k.pos.as<uint32_t>(),
-                               k.cnt.as<uint32_t>(), k.compute),
-          "dbhip_join_probe_u32");
+    if (m.opt.radix_local) {
+      db_ok(dbhip_join_radix_partition_u32(0, k.build.as<uint32_t>(), nullptr, k.n_local, k.n_local, k.n_local, k.join_ws.p,
+                                           k.join_ws.bytes, k.compute), "dbhip_join_radix_partition_u32");
+      hip_ok(hipEventRecord(k.ev_build, k.compute), "hipEventRecord");
+      db_ok(dbhip_join_radix_partition_u32(1, k.probe.as<uint32_t>(), nullptr, k.n_local, k.n_local, k.n_local, k.join_ws.p,
+                                           k.join_ws.bytes, k.compute), "dbhip_join_radix_partition_u32");
+      db_ok(dbhip_join_radix_match_u32(k.n_local, k.n_local, k.ids.as<uint32_t>(), k.out_rid.as<uint32_t>(),
+                                       k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(), k.join_ws.p, k.join_ws.bytes, k.compute),
+            "dbhip_join_radix_match_u32");
+    } else {
+      db_ok(dbhip_join_build_u32(k.build.as<uint32_t>(), k.n_local, k.ids.as<uint32_t>(), k.join_ws.p, k.join_ws.bytes, k.compute),
+            "dbhip_join_build_u32");
+      hip_ok(hipEventRecord(k.ev_build, k.compute), "hipEventRecord");
+      db_ok(dbhip_join_probe_u32(k.probe.as<uint32_t>(), k.n_local, k.join_ws.p, k.n_local, k.pos.as<uint32_t>(),
+                                 k.cnt.as<uint32_t>(), k.compute),
+            "dbhip_join_probe_u32");
+    }
     hip_ok(hipEventRecord(k.ev_done, k.compute), "hipEventRecord");
     hip_ok(hipEventSynchronize(k.ev_build), "hipEventSynchronize");
     t.until_build_done = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
@@ -437,9 +466,14 @@ StepTimes Engine::step() {
       for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xr, 0), "hipStreamWaitEvent");
     }
     hip_ok(hipEventRecord(k->ev_build0, k->compute), "hipEventRecord");
-    db_ok(dbhip_join_build_pairs_u32(k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->ids.as<uint32_t>(), k->join_ws.p,
-                                     k->join_ws.bytes, k->compute),
-          "dbhip_join_build_pairs_u32");
+    if (m.opt.radix_local)  // the received build pairs into the local partitions (the probe side's size is not known yet:
+                            // the build side's part of the workspace does not depend on it)
+      db_ok(dbhip_join_radix_partition_u32(0, k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->recv_r, 0, k->join_ws.p,
+                                           k->join_ws.bytes, k->compute), "dbhip_join_radix_partition_u32");
+    else
+      db_ok(dbhip_join_build_pairs_u32(k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->ids.as<uint32_t>(),
+                                       k->join_ws.p, k->join_ws.bytes, k->compute),
+            "dbhip_join_build_pairs_u32");
     hip_ok(hipEventRecord(k->ev_build, k->compute), "hipEventRecord");
   }
   for (auto &k : m.ranks) {
@@ -460,9 +494,17 @@ StepTimes Engine::step() {
       for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xs, 0), "hipStreamWaitEvent");
     }
     hip_ok(hipEventRecord(k->ev_probe0, k->compute), "hipEventRecord");
-    db_ok(dbhip_join_probe_u32(k->sk.as<uint32_t>(), k->recv_s, k->join_ws.p, k->recv_r, k->pos.as<uint32_t>(),
-                               k->cnt.as<uint32_t>(), k->compute),
-          "dbhip_join_probe_u32");
+    if (m.opt.radix_local) {
+      db_ok(dbhip_join_radix_partition_u32(1, k->sk.as<uint32_t>(), k->sr.as<uint32_t>(), k->recv_s, k->recv_r, k->recv_s,
+                                           k->join_ws.p, k->join_ws.bytes, k->compute), "dbhip_join_radix_partition_u32");
+      db_ok(dbhip_join_radix_match_u32(k->recv_r, k->recv_s, k->ids.as<uint32_t>(), k->out_rid.as<uint32_t>(),
+                                       k->pos.as<uint32_t>(), k->cnt.as<uint32_t>(), k->join_ws.p, k->join_ws.bytes, k->compute),
+            "dbhip_join_radix_match_u32");
+    } else {
+      db_ok(dbhip_join_probe_u32(k->sk.as<uint32_t>(), k->recv_s, k->join_ws.p, k->recv_r, k->pos.as<uint32_t>(),
+                                 k->cnt.as<uint32_t>(), k->compute),
+            "dbhip_join_probe_u32");
+    }
     hip_ok(hipEventRecord(k->ev_done, k->compute), "hipEventRecord");
   }
   for (auto &k : m.ranks) {
@@ -520,11 +562,30 @@ CheckReport Engine::check() {
       db_ok(dbhip_radix_sort_u32(sorted.as<uint32_t>(), tmp.as<uint32_t>(), k.recv_r, 8, sort_ws.p, sort_ws.bytes, s),
             "dbhip_radix_sort_u32");
     }
+    // radix local join: results come in the probe side's partition order with their row ids: the probe keys are
+    // regenerated in that order, and the row ids must be exactly the received ones (multiset fingerprint / permutation)
+    DevMem pk_result, perm_ws;
+    const uint32_t *pk_aligned = pkeys;
+    if (m.opt.radix_local) {
+      pk_result.reserve(k.device, k.recv_s * 4);
+      db_ok(dbhip_gen_uniform_at_u32(pk_result.as<uint32_t>(), k.out_rid.as<uint32_t>(), k.recv_s, m.opt.probe_seed, 0, key_hi, s),
+            "dbhip_gen_uniform_at_u32");
+      pk_aligned = pk_result.as<uint32_t>();
+      if (m.direct) {
+        const size_t pb = dbhip_check_permutation_workspace_bytes(k.recv_s);
+        perm_ws.reserve(k.device, pb);
+        db_ok(dbhip_check_permutation_u32(k.out_rid.as<uint32_t>(), k.recv_s, res + 8, perm_ws.p, perm_ws.bytes, s),
+              "dbhip_check_permutation_u32");
+      } else {
+        db_ok(dbhip_check_sorted_u32(k.out_rid.as<uint32_t>(), k.recv_s, 0, res + 8, s), "dbhip_check_sorted_u32");
+        db_ok(dbhip_check_sorted_u32(k.sr.as<uint32_t>(), k.recv_s, 0, res + 12, s), "dbhip_check_sorted_u32");
+      }
+    }
     if (m.direct)  // local row indices: the key of an id is a lookup
-      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pkeys, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
+      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pk_aligned, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
                                  k.ids.as<uint32_t>(), bkeys, 0, 0, 0, res + 4, s), "dbhip_check_join_u32");
     else
-      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pkeys, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
+      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pk_aligned, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
                                  k.ids.as<uint32_t>(), nullptr, m.opt.build_seed, 0, key_hi, res + 4, s), "dbhip_check_join_u32");
     hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize");
     const auto h = d2h<uint64_t>(res, 40, k.device);
@@ -539,6 +600,10 @@ CheckReport Engine::check() {
       rep.sent_rows += 2 * k.n_local - Impl::cell(k, m.P, 0, k.id, k.id) - Impl::cell(k, m.P, 1, k.id, k.id);
     }
     rep.bad_rows += h[4];
+    if (m.opt.radix_local) {  // the result's row ids are the received ones, each once
+      if (m.direct) rep.bad_rows += h[8];
+      else if (h[9] != h[13] || h[10] != h[14]) rep.bad_rows += k.recv_s ? k.recv_s : 1;
+    }
     rep.matches += h[5];
     rep.recv_build += k.recv_r;
     rep.recv_probe += k.recv_s;
@@ -571,7 +636,17 @@ Engine::HostShard Engine::download(unsigned i) const {
   Impl &m = *impl_;
   Rank &k = m.local(i);
   HostShard h;
-  if (m.direct) {
+  const uint32_t key_hi = static_cast<uint32_t>(m.n ? m.n - 1 : 0);
+  if (m.opt.radix_local) {  // results in the probe side's partition order: row ids from the join, keys regenerated
+    h.probe_row_ids = d2h<uint32_t>(k.out_rid.p, k.recv_s, k.device);
+    DevMem pk;
+    pk.reserve(k.device, k.recv_s * 4);
+    m.set(k);
+    db_ok(dbhip_gen_uniform_at_u32(pk.as<uint32_t>(), k.out_rid.as<uint32_t>(), k.recv_s, m.opt.probe_seed, 0, key_hi, k.compute),
+          "dbhip_gen_uniform_at_u32");
+    hip_ok(hipStreamSynchronize(k.compute), "hipStreamSynchronize");
+    h.probe_keys = d2h<uint32_t>(pk.p, k.recv_s, k.device);
+  } else if (m.direct) {
     h.probe_keys = d2h<uint32_t>(k.probe.p, k.n_local, k.device);
     h.probe_row_ids.resize(k.n_local);
     for (size_t j = 0; j < k.n_local; ++j) h.probe_row_ids[j] = static_cast<uint32_t>(k.lo + j);
@@ -619,6 +694,8 @@ extern "C" void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned w
                                      int direct_single) {
   try {
     pjoin::Options o;
+    const char *local = std::getenv("DWARF_BENCH_PJOIN_LOCAL");
+    o.radix_local = !(local && std::string(local) == "probe");
     o.world = world;
     o.all_local = false;
     o.rank = rank;

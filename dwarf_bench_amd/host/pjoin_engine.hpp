@@ -2,8 +2,9 @@
 // the reference is single-device).  JoinOmnisci semantics (join/join_omnisci.cpp:49-118) over key columns sharded
 // across `world` ranks, one rank per GPU:
 //
-//     compute stream :  partition R |            partition S | build R            | probe S
+//     compute stream :  partition R |            partition S | local partition R' | local partition S' + match
 //     exchange stream:          counts R | exchange R | counts S | exchange S |
+// (local join = the radix join of include/dbhip.h; with Options::radix_local = false: build R | probe S)
 //
 // Per rank two HIP streams and events between them; the only host waits inside a step are the two tiny count
 // gathers (the receive sizes must be host integers) and the final sync.  The exchange is ONE RCCL group of
@@ -34,6 +35,8 @@ struct Options {
   const void *nccl_id = nullptr;  // all_local == false: the 128-byte ncclUniqueId every rank passes
   bool force_copy = false;     // all_local: exchange by hipMemcpyPeerAsync even where RCCL could be used
   bool direct_single = false;  // world == 1: plain local join without partition / exchange
+  bool radix_local = true;     // local join = the radix join (both received sides partitioned alike, fused LDS build +
+                               // probe, no table in HBM); false: build + row-ordered probe (the first implementation)
   uint64_t build_seed = 42, probe_seed = 43;  // columns: key_i = mix64(seed, i) % n_total (SURVEY 8d join regime)
 };
 

@@ -8,14 +8,14 @@ Per rank, with local shards of the build (R) and probe (S) key columns and their
                 whom), hence its receive sizes and — identically on all ranks — the number of exchange rounds;
   3. exchange   all_to_all of the pairs (RCCL: every GPU sends 1/P of its rows to each peer, one peer per
                 xGMI link, all links busy at once), one collective per column (keys, row ids);
-  4. local join dwarf 4a on the received pairs (dbhip_join_build_pairs_u32 / dbhip_join_probe_u32): the id
-                buffer holds GLOBAL build row ids.
+  4. local join dwarf 4a on the received pairs as a radix join (dbhip_join_radix_*): the id buffer holds GLOBAL
+                build row ids, the probe rows come back with their global row ids.
 Results stay sharded by key hash: per rank (probe global row id, offset, count) + the id buffer.
 
 The steps of the two relations are interleaved so that the xGMI exchange hides behind HBM-bound kernels
 (collectives are issued async: they run on RCCL's own stream, `wait()` only makes the compute stream wait):
 
-    compute stream :  partition R |            partition S | build R            | probe S
+    compute stream :  partition R |            partition S | local partition R' | local partition S' + match
     RCCL stream    :          counts R | exchange R | counts S | exchange S |
 
 The host blocks twice, on the two tiny count gathers (split sizes must be host integers).
@@ -33,7 +33,10 @@ import torch.distributed as dist
 
 
 class HipBackend:
-    """device steps on the local GPU through the C ABI (dwarf_bench_amd.ops)"""
+    """device steps on the local GPU through the C ABI (dwarf_bench_amd.ops).  The local join is the radix join
+    (dbhip_join_radix_*): the received pairs of both sides are partitioned once more with the same geometry and ONE
+    launch builds and probes every partition's sub-table in LDS — the results come in the probe side's partition
+    order together with their row ids, which is all a sharded result needs."""
 
     def partition(self, keys: torch.Tensor, first_row_id: int, parts: int):
         from . import ops
@@ -42,17 +45,19 @@ class HipBackend:
     def build(self, build_keys: torch.Tensor, build_row_ids: torch.Tensor | None, n_probe: int):
         """-> plan; the id buffer holds build_row_ids values when given (global row ids), else local indices"""
         from . import ops
-        plan = ops.HashJoin(build_keys.numel(), n_probe, build_keys.device)
-        plan.build(build_keys, build_row_ids)
+        plan = ops.RadixJoin(build_keys.numel(), n_probe, build_keys.device)
+        plan.partition_build(build_keys, build_row_ids)
         return plan
 
-    def probe(self, plan, probe_keys: torch.Tensor):
-        """-> pos, cnt, ids"""
-        plan.probe(probe_keys)
+    def probe(self, plan, probe_keys: torch.Tensor, probe_row_ids: torch.Tensor | None):
+        """-> probe row ids (in result order), pos, cnt, ids"""
+        plan.partition_probe(probe_keys, probe_row_ids)
+        plan.match()
         return plan.result()
 
-    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None):
-        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
+    def local_join(self, build_keys: torch.Tensor, probe_keys: torch.Tensor, build_row_ids: torch.Tensor | None = None,
+                   probe_row_ids: torch.Tensor | None = None):
+        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys, probe_row_ids)
 
     def column_sum(self, col: torch.Tensor) -> int:
         """wrap-around (mod 2^32) sum of a column, on the device (dbhip_reduce_sum_i32)"""
@@ -208,9 +213,8 @@ def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_f
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
-        pos, cnt, ids = backend.local_join(build_keys, probe_keys)
-        dev = probe_keys.device
-        rid = torch.arange(probe_first_row, probe_first_row + probe_keys.numel(), dtype=torch.int64, device=dev).to(torch.int32)
+        rid, pos, cnt, ids = backend.local_join(build_keys, probe_keys)  # row ids = local indices, in result order
+        rid = rid if probe_first_row == 0 else (rid.to(torch.int64) + probe_first_row).to(torch.int32)
         ids_global = ids if build_first_row == 0 else (ids.to(torch.int64) + build_first_row).to(torch.int32)
         return PartitionedJoinResult(rid, pos, cnt, ids_global, 0, build_keys.numel(), probe_keys.numel())
 
@@ -228,8 +232,8 @@ def partitioned_join(build_keys: torch.Tensor, probe_keys: torch.Tensor, build_f
     rk_in, rr_in = rk_x.wait(), rr_x.wait()
     plan = backend.build(rk_in, rr_in, int(sum(s_recv)))
     sk_in, sr_in = sk_x.wait(), sr_x.wait()
-    pos, cnt, ids_global = backend.probe(plan, sk_in)
+    rid_out, pos, cnt, ids_global = backend.probe(plan, sk_in, sr_in)
     if verify_exchange:
         _verify_exchange(backend, (rk, rr, sk, sr), (rk_in, rr_in, sk_in, sr_in), group)
     sent = int(sum(r_send) - r_send[rank] + sum(s_send) - s_send[rank])
-    return PartitionedJoinResult(sr_in, pos, cnt, ids_global, sent, rk_in.numel(), sk_in.numel())
+    return PartitionedJoinResult(rid_out, pos, cnt, ids_global, sent, rk_in.numel(), sk_in.numel())

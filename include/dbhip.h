@@ -73,6 +73,10 @@ int dbhip_workspace_status(const void *workspace, uint32_t *host_status, dbhip_s
  * element i of the logical column = lo + mix64(seed, first_index + i) % (hi - lo + 1)            */
 int dbhip_gen_uniform_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t first_index,
                           uint32_t lo, uint32_t hi, dbhip_stream_t stream);
+/* the same column read at given positions: out[i] = lo + mix64(seed, indices[i]) % (hi - lo + 1) (a key column
+ * regenerated in the order of a list of row ids: the partitioned join's checks) */
+int dbhip_gen_uniform_at_u32(uint32_t *out, const uint32_t *indices, size_t n, uint64_t seed, uint32_t lo, uint32_t hi,
+                             dbhip_stream_t stream);
 /* unique ascending keys in [0, 10*N): element i = 10*(first_index+i) + mix64(seed, first_index+i) % 10
  * (same shape as helpers::make_unique_random, common/common.cpp:7-20) */
 int dbhip_gen_unique_sorted_u32(uint32_t *out, size_t n, uint64_t seed, uint64_t first_index,

@@ -38,7 +38,7 @@ class OracleBackend:
     def build(self, build_keys, build_row_ids, n_probe):
         return (build_keys, build_row_ids)
 
-    def probe(self, plan, probe_keys):
+    def probe(self, plan, probe_keys, probe_row_ids=None):
         build_keys, build_row_ids = plan
         b = build_keys.numpy().view(np.uint32)
         p = probe_keys.numpy().view(np.uint32)
@@ -46,10 +46,12 @@ class OracleBackend:
         if build_row_ids is not None:
             ids = build_row_ids.numpy().view(np.uint32)[ids.astype(np.int64)]
         t = lambda a: torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
-        return t(pos), t(cnt), t(ids)
+        if probe_row_ids is None:
+            probe_row_ids = t(np.arange(p.size, dtype=np.uint32))
+        return probe_row_ids, t(pos), t(cnt), t(ids)
 
-    def local_join(self, build_keys, probe_keys, build_row_ids=None):
-        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys)
+    def local_join(self, build_keys, probe_keys, build_row_ids=None, probe_row_ids=None):
+        return self.probe(self.build(build_keys, build_row_ids, probe_keys.numel()), probe_keys, probe_row_ids)
 
     def column_sum(self, col):
         return int(col.numpy().view(np.uint32).astype(np.uint64).sum()) & 0xFFFFFFFF
