@@ -205,6 +205,30 @@ def bench_join(steps, warmup, log2n=26):
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 
+def bench_join_radix(steps, warmup, log2n=26):
+    """the same join as a radix join (dbhip_join_radix_*): both sides partitioned alike, one fused LDS build + probe
+    launch; results in the probe side's partition order with row ids — what the partitioned multi-GPU join runs per rank"""
+    from dwarf_bench_amd import ops
+    n = 1 << log2n
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    plan = ops.RadixJoin(n, n)
+
+    def run():
+        plan.partition_build(build)
+        plan.partition_probe(probe)
+        plan.match()
+
+    for _ in range(max(1, warmup)):
+        run()
+    us = _drop_max_mean(_event_times_us(run, steps))
+    plan.result()
+    alg = 24 * n  # keys of both sides in, ids out, (row id, position, count) per probe row out
+    return {"rows": 2 * n, "kernel_us": us, "mrows_per_s": 2 * n / us, "algorithmic_bytes": alg,
+            "achieved_gbs": alg / us / 1e3, "frac_of_hbm_peak": alg / us / 1e3 / HBM_PEAK_GBS,
+            "workload": f"HashJoin 2^{log2n} x 2^{log2n} uint32 keys as a radix join (results with row ids, partition order)"}
+
+
 def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
     """Radix-partitioned hash join of 2^log2_total x 2^log2_total rows over all ranks (strong scaling: the total
     is fixed, every rank holds a contiguous 1/P shard of both key columns, generated in place)."""
@@ -527,6 +551,8 @@ def main():
             dwarfs["groupby"] = bench_groupby(k, 2)
         if args.dwarf in ("all", "join"):
             dwarfs["join"] = bench_join(max(3, k // 2), 2)
+            torch.cuda.empty_cache()
+            dwarfs["join_radix"] = bench_join_radix(max(3, k // 2), 2)
             torch.cuda.empty_cache()
             if not args.no_pjoin:
                 # the single-GPU point of the partitioned join's scaling curve: C++ host (the dwarf's engine), and the
