@@ -31,7 +31,7 @@ DWARFS = {
     "sort_4bit": (r"rs_\w+<4", r"rs_histogram", True),
     "groupby": (r"gb_aggregate_kernel|gb_reduce_kernel", r"gb_aggregate_kernel", True),
     # join: 4-B/lane reads and random 16-B gathers — widths the guide calls uncalibrated: raw counter, not doubled
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel", r"jl_build_kernel", False),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_build_kernel<false>", False),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", False),
 }
 
@@ -61,8 +61,10 @@ CONFIGS = {
     "sort_2p24_8bit": (r"rs_\w+<8|rs_finalize", r"rs_histogram_kernel<8", r"rs_finalize_kernel"),
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
     "groupby_2p26_2p16": (r"gb_aggregate_kernel|gb_reduce_kernel", r"gb_aggregate_kernel", r"gb_reduce_kernel"),
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel", r"jl_hist0_kernel", r"jl_build_kernel"),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_hist0_kernel", r"jl_build_kernel<false>"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
+    # the radix join: both sides through the partitioner, then the fused build + probe launch
+    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>", r"jl_hist0_kernel", r"jl_build_kernel<true>"),
 }
 
 
@@ -80,7 +82,8 @@ def headline(raw: Path, matches_scan: float = 4.034e-4):
     """per configuration: kernels {dispatches, avg_us, min_us} and the per-call span, from the chronological trace"""
     rows = read_trace(raw)
     alg = {"scan_2p28": 4 * N_SCAN * (1 + matches_scan), "sort_2p24_8bit": 8 * N_SORT, "sort_2p24_4bit": 8 * N_SORT,
-           "groupby_2p26_2p16": 8 * N_GB + 4 * GROUPS, "join_build": None, "join_probe": None}
+           "groupby_2p26_2p16": 8 * N_GB + 4 * GROUPS, "join_build": None, "join_probe": None,
+           "join_radix_2p26": 24 * N_JOIN}
     out = {}
     for name, (pat, first, last) in CONFIGS.items():
         mine = [r for r in rows if re.search(pat, r[2])]
