@@ -202,12 +202,17 @@ __global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned 
 constexpr size_t jl_scatter_lds_bytes(unsigned nb) {
   return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + sizeof(unsigned) * kJlWaves;
 }
-template <int LEVEL, bool RANK = false>
+struct JlNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// before_stores(): called once, right before the tile's global stores are issued (the level-0 kernel waits there for
+// the next tile's prefetched keys: see jl_scatter0_kernel)
+template <int LEVEL, bool RANK = false, class Hook = JlNoHook>
 __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], const unsigned (&rid)[kJlKpt],
                                                 const unsigned (&dest)[kJlKpt], unsigned nb, unsigned parts,
                                                 unsigned arg, unsigned long long *cursors,
                                                 unsigned *__restrict__ out_keys, unsigned *__restrict__ out_rids,
-                                                unsigned *s_mem) {
+                                                unsigned *s_mem, Hook before_stores = Hook()) {
   unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_mem);  // 8-byte aligned first
   unsigned *s_cnt = s_mem + 2 * nb;
   unsigned *s_excl = s_cnt + nb;
@@ -260,6 +265,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
     }
   }
   __syncthreads();
+  before_stores();
   for (unsigned p = tid; p < total; p += kJlThreads) {
     const unsigned k = s_keys[p];
     const unsigned pid = jl_pid_sel<RANK>(k, parts);
@@ -290,26 +296,71 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
   // blockIdx, so XCD x = blockIdx % 8 takes the tile groups g with g % 8 == x.  A (group, bucket) write frontier is
   // then advanced by ONE XCD, whose L2 merges the partial lines of consecutive runs before they leave for memory
   // (WRITE_SIZE 770 MB for 537 MB stored when every XCD touched every frontier; 338 -> 310 us at 2^26 rows).
-  // The same slicing of the level-1 scatter (buckets b % 8 == x per XCD, persistent grid) measured no faster, and
-  // requesting the next tile's keys before the current tile is processed cost occupancy: 310 -> 370 us.
+  // The same slicing of the level-1 scatter (buckets b % 8 == x per XCD, persistent grid) measured no faster.
   const size_t tpg = jl_tiles_per_group(n);
   const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u, per_xcd = gridDim.x / 8u;  // host: grid % 8 == 0
-  for (size_t local = slot; local < (kJlGroups / 8) * tpg; local += per_xcd) {
-    const size_t group_of_tile = (local / tpg) * 8 + xcd;
-    const size_t tile = group_of_tile * tpg + local % tpg;
-    if (tile >= tiles) continue;
-    const size_t base = tile * kJlTile;
-    unsigned key[kJlKpt], rid[kJlKpt], dest[kJlKpt];
+  const size_t locals = (kJlGroups / 8) * tpg;
+  // tile of the workgroup's `local`-th step, or `tiles` when that step has none (the ragged end of the last group)
+  auto tile_of = [&](size_t local, size_t *group) -> size_t {
+    *group = (local / tpg) * 8 + xcd;
+    const size_t tile = *group * tpg + local % tpg;
+    return local < locals && tile < tiles ? tile : tiles;
+  };
+  auto load_tile = [&](size_t tile, unsigned (&k)[kJlKpt], unsigned (&r)[kJlKpt]) {
 #pragma unroll
     for (int j = 0; j < kJlKpt; ++j) {
-      const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
-      const bool valid = idx < n;
-      key[j] = valid ? keys[idx] : 0u;
-      rid[j] = valid ? (row_ids ? row_ids[idx] : static_cast<unsigned>(first_row + idx)) : 0u;
-      dest[j] = valid ? jl_pid_sel<RANK>(key[j], parts) >> k2_shift : k1;
+      const size_t idx = tile * kJlTile + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+      const bool valid = tile < tiles && idx < n;
+      k[j] = valid ? keys[idx] : 0u;
+      r[j] = valid && row_ids ? row_ids[idx] : 0u;
     }
-    // this tile bumps only its group's cursors
-    jl_scatter_tile<0, RANK>(key, rid, dest, k1, parts, k2_shift, cursors + group_of_tile * k1, out_keys, out_rids, s_mem);
+  };
+  // The next tile's keys are requested before the current tile's LDS work and waited for right before the current
+  // tile's stores go out (vmcnt counts a wave's loads and stores in issue order: waiting for loads at the top of the
+  // next step would also wait for every store of this one).  They cross the loop in registers moved by a v_mov the
+  // compiler cannot see through — a loop-carried register that a load defined is waited for with vmcnt(0) at first use.
+  unsigned ckey[kJlKpt], crid[kJlKpt];
+  size_t group = 0, tile = tile_of(slot, &group);
+  load_tile(tile, ckey, crid);
+#pragma unroll
+  for (int j = 0; j < kJlKpt; ++j) {
+    asm volatile("v_mov_b32 %0, %0" : "+v"(ckey[j]));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(crid[j]));
+  }
+  for (size_t local = slot; local < locals; local += per_xcd) {
+    size_t ngroup = 0;
+    const size_t ntile = tile_of(local + per_xcd, &ngroup);
+    unsigned nkey[kJlKpt], nrid[kJlKpt], mkey[kJlKpt], mrid[kJlKpt];
+    load_tile(ntile, nkey, nrid);
+    auto wait_next = [&]() {
+#pragma unroll
+      for (int j = 0; j < kJlKpt; ++j) {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mkey[j]) : "v"(nkey[j]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mrid[j]) : "v"(nrid[j]));
+      }
+    };
+    if (tile < tiles) {  // uniform over the workgroup
+      const size_t base = tile * kJlTile;
+      unsigned rid[kJlKpt], dest[kJlKpt];
+#pragma unroll
+      for (int j = 0; j < kJlKpt; ++j) {
+        const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+        const bool valid = idx < n;
+        rid[j] = valid ? (row_ids ? crid[j] : static_cast<unsigned>(first_row + idx)) : 0u;
+        dest[j] = valid ? jl_pid_sel<RANK>(ckey[j], parts) >> k2_shift : k1;
+      }
+      // this tile bumps only its group's cursors
+      jl_scatter_tile<0, RANK>(ckey, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem, wait_next);
+    } else {
+      wait_next();
+    }
+#pragma unroll
+    for (int j = 0; j < kJlKpt; ++j) {
+      ckey[j] = mkey[j];
+      crid[j] = mrid[j];
+    }
+    tile = ntile;
+    group = ngroup;
   }
 }
 
@@ -386,7 +437,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const u32x2 *__
 // pairs (the level-1 output): prids == nullptr means pkeys points at pairs.
 __device__ __forceinline__ u32x2 jl_row(const unsigned *__restrict__ pkeys, const unsigned *__restrict__ prids,
                                         size_t i) {
-  if (prids) return u32x2{pkeys[i], prids[i]};
+  (void)prids;  // both scatter levels write (key, row id) pairs
   return reinterpret_cast<const u32x2 *>(pkeys)[i];
 }
 
@@ -445,7 +496,8 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
   // a partition holds ~kJlRowsPerPart rows (+ 6 sigma of a Poisson count): rows per thread whose slot and row id
   // stay in registers between steps 1 and 3, and rows per thread loaded one partition ahead
   constexpr int kJlCached = static_cast<int>((kJlRowsPerPart + kJlRowsPerPart / 8 + kJlBuildThreads - 1) / kJlBuildThreads);
-  constexpr int kJlPre = static_cast<int>(kJlRowsPerPart / kJlBuildThreads);
+  constexpr int kJlPre = kJlCached;  // every cached row comes from the prefetch: a row loaded inside the claim phase made
+                                     // the compiler wait (s_waitcnt vmcnt(0)) for the prefetch issued just before it too
   static_assert(static_cast<unsigned>(kJlCached) * kJlBuildThreads <= kJlSubSlots, "a partition without overflow rows fits the id staging area");
 
   // Persistent workgroups walk the partitions with a stride of the grid; a workgroup is a chain of dependent
@@ -454,11 +506,16 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
   size_t part = blockIdx.x;
   if (part >= parts) return;
   size_t lo = starts[part], hi = starts[part + 1];
-  u32x2 pre[kJlPre];
+  u32x2 carry[kJlPre];  // the current partition's rows, in registers that no load is pending on
 #pragma unroll
   for (int r = 0; r < kJlPre; ++r) {
     const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
-    pre[r] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+    carry[r] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+  }
+#pragma unroll
+  for (int r = 0; r < kJlPre; ++r) {  // (see below: the loop must not carry a register that a load defined)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(carry[r].x));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(carry[r].y));
   }
   while (true) {
     for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
@@ -467,16 +524,19 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     }
     u32x2 cur[kJlPre];
 #pragma unroll
-    for (int r = 0; r < kJlPre; ++r) cur[r] = pre[r];
+    for (int r = 0; r < kJlPre; ++r) cur[r] = carry[r];
     const size_t npart = part + gridDim.x;
     size_t nlo = 0, nhi = 0;
+    u32x2 pre[kJlPre];  // the next partition's rows, in flight
+#pragma unroll
+    for (int r = 0; r < kJlPre; ++r) pre[r] = u32x2{0u, 0u};
     if (npart < parts) {
       nlo = starts[npart];
       nhi = starts[npart + 1];
 #pragma unroll
       for (int r = 0; r < kJlPre; ++r) {
         const size_t i = nlo + tid + static_cast<size_t>(r) * kJlBuildThreads;
-        pre[r] = i < nhi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+        if (i < nhi) pre[r] = jl_row(pkeys, prids, i);
       }
     }
     // radix join: this partition's first probe rows (four consecutive ones per lane) are requested now and arrive
@@ -548,6 +608,17 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     }
     if (tid == kJlBuildThreads - 1) s_end = run;
     JL_BUILD_BARRIER();
+    // vmcnt counts loads and stores of a wave in issue order: the next partition's rows (requested at the top of this
+    // iteration) are waited for HERE, while nothing but those loads is outstanding — at the top of the next iteration
+    // the wait would also cover every store issued below, i.e. a full store drain per partition
+    // (the rows move on through a v_mov the compiler cannot see through: a loop-carried register that a load defined
+    //  is waited for with vmcnt(0) at the loop head whatever happened in between)
+    u32x2 nxt[kJlPre];
+#pragma unroll
+    for (int r = 0; r < kJlPre; ++r) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(nxt[r].x) : "v"(pre[r].x));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(nxt[r].y) : "v"(pre[r].y));
+    }
     if (!kMatch) {
     // 3. publish the sub-table: {key, first position | count field} for every slot.  Positions are an exclusive scan
     //    in slot order, so slot i ends where slot i+1 starts (the last one at s_end).  Output stores are what this
@@ -662,40 +733,95 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     part = npart;
     lo = nlo;
     hi = nhi;
+#pragma unroll
+    for (int r = 0; r < kJlPre; ++r) carry[r] = nxt[r];
   }
 }
 
+// one probe row: slot {key, first position | count field} by linear probing inside the key's sub-table
+__device__ __forceinline__ void jl_probe_row(unsigned key, const u32x2 *__restrict__ table, unsigned parts, unsigned pos_bits,
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out) {
+  const unsigned h = fmix32(key);
+  const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+  unsigned s = jl_home_slot(h), pos = 0, cnt = 0;
+  for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {  // the sentinel never matches
+    const u32x2 e = sub[s];
+    if (e.x == key) {
+      pos = e.y & pos_mask;
+      const unsigned field = pos_bits < 32 ? e.y >> pos_bits : 0u;
+      // s + 1 may be the first slot of the next sub-table (or the sentinel): positions run on across them
+      cnt = field < cnt_esc ? field + 1u : (sub[s + 1].y & pos_mask) - pos;
+      break;
+    }
+    if (e.x == kEmptyKey) break;
+    s = jl_next_slot(s);
+  }
+  *pos_out = pos;
+  *cnt_out = cnt;
+}
+
+#ifndef DBHIP_JL_PROBE_ROWS
+#define DBHIP_JL_PROBE_ROWS 1  // 4 consecutive rows per lane (16-byte key loads / result stores, four gathers in flight per
+#endif                         // lane) measured SLOWER: 1852 vs 1434 us at 2^26 — the random-access path saturates sooner
 __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
                                                               const u32x2 *__restrict__ table, unsigned parts,
                                                               unsigned pos_bits, unsigned *__restrict__ out_pos,
                                                               unsigned *__restrict__ out_cnt) {
-  // one row per lane per step at full occupancy (32 waves per CU): the probe is pure memory latency, one random
-  // 8-byte gather per row = the slot {key, first position | count field}; the right-hand neighbour is read only
-  // when the field holds the escape value.  (The first layout read slot and neighbour with one 16-byte load at
-  // 8-byte alignment: every eighth row crossed a 64-byte line, i.e. one more memory request; unrolling rows per
-  // lane measured slower, 2.1 vs 1.7 ms at 2^26.)
-  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  // The probe is pure memory latency: one random 8-byte gather per row = the slot {key, first position | count
+  // field}; the right-hand neighbour is read only when the field holds the escape value.  (The first layout read
+  // slot and neighbour with one 16-byte load at 8-byte alignment: every eighth row crossed a 64-byte line, i.e. one
+  // more memory request.)  A lane takes kRows CONSECUTIVE rows per step: one 16-byte key load, kRows gathers in
+  // flight, one 16-byte store per output column — with one row per step every gather was preceded by a key load and
+  // followed by a drain of the two 4-byte stores (vmcnt counts loads and stores together, in issue order).
+  constexpr int kRows = DBHIP_JL_PROBE_ROWS;
+  typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
   const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
   const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
-    const unsigned key = probe[i];
-    const unsigned h = fmix32(key);
-    const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
-    unsigned s = jl_home_slot(h), pos = 0, cnt = 0;
-    for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {  // the sentinel never matches
-      const u32x2 e = sub[s];
-      if (e.x == key) {
-        pos = e.y & pos_mask;
-        const unsigned field = pos_bits < 32 ? e.y >> pos_bits : 0u;
-        // s + 1 may be the first slot of the next sub-table (or the sentinel): positions run on across them
-        cnt = field < cnt_esc ? field + 1u : (sub[s + 1].y & pos_mask) - pos;
-        break;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  if (kRows == 4) {
+    const size_t quads = n / 4;
+    for (size_t q = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; q < quads; q += stride) {
+      const u32x4 k = *reinterpret_cast<const u32x4_a4 *>(probe + 4 * q);
+      const unsigned key[4] = {k.x, k.y, k.z, k.w};
+      // the four first-step gathers go out together; rows whose first slot is neither their key nor empty continue
+      // on their own below
+      const u32x2 *sub[4];
+      unsigned s0[4];
+      u32x2 e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned h = fmix32(key[r]);
+        sub[r] = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+        s0[r] = jl_home_slot(h);
+        e[r] = sub[r][s0[r]];
       }
-      if (e.x == kEmptyKey) break;
-      s = jl_next_slot(s);
+      unsigned pos[4], cnt[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pos[r] = cnt[r] = 0;
+        if (key[r] == kEmptyKey) continue;
+        unsigned s = s0[r];
+        u32x2 cur = e[r];
+        for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
+          if (cur.x == key[r]) {
+            pos[r] = cur.y & pos_mask;
+            const unsigned field = pos_bits < 32 ? cur.y >> pos_bits : 0u;
+            cnt[r] = field < cnt_esc ? field + 1u : (sub[r][s + 1].y & pos_mask) - pos[r];
+            break;
+          }
+          if (cur.x == kEmptyKey) break;
+          s = jl_next_slot(s);
+          cur = sub[r][s];
+        }
+      }
+      *reinterpret_cast<u32x4_a4 *>(out_pos + 4 * q) = u32x4{pos[0], pos[1], pos[2], pos[3]};
+      *reinterpret_cast<u32x4_a4 *>(out_cnt + 4 * q) = u32x4{cnt[0], cnt[1], cnt[2], cnt[3]};
     }
-    out_pos[i] = pos;
-    out_cnt[i] = cnt;
+    const size_t i = quads * 4 + static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x;  // the n % 4 last rows
+    if (i < n) jl_probe_row(probe[i], table, parts, pos_bits, pos_mask, cnt_esc, out_pos + i, out_cnt + i);
+  } else {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
+      jl_probe_row(probe[i], table, parts, pos_bits, pos_mask, cnt_esc, out_pos + i, out_cnt + i);
   }
 }
 
@@ -841,6 +967,8 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
                        rows_a, starts0, parts, k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,
                        cursors1);
+    // (one tile per workgroup; a persistent grid with the next tile's rows prefetched — what helps the level-0
+    //  scatter — measured the same here: a workgroup that ends after its stores never waits for them)
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, rows_a, starts0, tstarts0,
                        parts, k1, k2, cursors1, rows_b);
     *out_pairs = reinterpret_cast<const unsigned *>(rows_b);
@@ -990,7 +1118,12 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
                    unsigned *out_pos, unsigned *out_cnt, hipStream_t s, const DeviceInfo &dev) {
   const JlLayout L = jl_layout(n_build);
   const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
-  hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
+  static const int wgs_per_cu = [] {
+    const char *e = getenv("DBHIP_JL_PROBE_WGS");  // experiment knob: workgroups per CU of the probe grid
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 64 ? v : 8;
+  }();
+  hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, wgs_per_cu)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
                      table, L.parts, jl_pos_bits(n_build), out_pos, out_cnt);
   return launch_status();
 }
