@@ -28,6 +28,9 @@ constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table i
 #ifndef DBHIP_GB_VEC
 #define DBHIP_GB_VEC 2
 #endif
+#ifndef DBHIP_GB_PIPE
+#define DBHIP_GB_PIPE 1
+#endif
 constexpr int kGbVecPerIter = DBHIP_GB_VEC;  // uint4 key + uint4 val loads in flight per lane per step (4 or 8: a few
                                              // us either way for one key range, 123 -> 146 us for two: the partner
                                              // workgroups drift apart and lose the shared read)
@@ -99,8 +102,9 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
   bool bad_key = false;
   const size_t n4 = n / 4;
   const size_t step = static_cast<size_t>(geo.chunk_slots) * THREADS * kGbVecPerIter;
-  for (size_t base = static_cast<size_t>(slot) * THREADS * kGbVecPerIter; base < n4; base += step) {
-    u32x4 k[kGbVecPerIter], v[kGbVecPerIter];
+  // software pipeline: the loads of step i+1 are issued before the LDS atomics of step i (DBHIP_GB_PIPE=0 compiles
+  // the plain load-then-add loop for A/B timing)
+  auto load_step = [&](size_t base, u32x4 (&k)[kGbVecPerIter], u32x4 (&v)[kGbVecPerIter]) {
 #pragma unroll
     for (int u = 0; u < kGbVecPerIter; ++u) {
       const size_t i = base + static_cast<size_t>(u) * THREADS + tid;
@@ -117,6 +121,8 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
         v[u] = u32x4{0u, 0u, 0u, 0u};
       }
     }
+  };
+  auto add_step = [&](size_t base, const u32x4 (&k)[kGbVecPerIter], const u32x4 (&v)[kGbVecPerIter]) {
 #pragma unroll
     for (int u = 0; u < kGbVecPerIter; ++u) {
       const unsigned kk[4] = {k[u].x, k[u].y, k[u].z, k[u].w};
@@ -129,7 +135,26 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
         bad_key |= live && kk[c] >= groups;
       }
     }
+  };
+  const size_t base0 = static_cast<size_t>(slot) * THREADS * kGbVecPerIter;
+#if DBHIP_GB_PIPE
+  u32x4 ka[kGbVecPerIter], va[kGbVecPerIter], kb[kGbVecPerIter], vb[kGbVecPerIter];
+  if (base0 < n4) load_step(base0, ka, va);
+  for (size_t base = base0; base < n4; base += 2 * step) {
+    const bool has_b = base + step < n4;
+    if (has_b) load_step(base + step, kb, vb);
+    add_step(base, ka, va);
+    if (!has_b) break;
+    if (base + 2 * step < n4) load_step(base + 2 * step, ka, va);
+    add_step(base + step, kb, vb);
   }
+#else
+  for (size_t base = base0; base < n4; base += step) {
+    u32x4 k[kGbVecPerIter], v[kGbVecPerIter];
+    load_step(base, k, v);
+    add_step(base, k, v);
+  }
+#endif
   // the n % 4 tail rows: first workgroup of every range
   if (slot == 0 && tid < (n & 3)) {
     const unsigned kk = keys[n4 * 4 + tid], vv = vals[n4 * 4 + tid];
