@@ -1,5 +1,5 @@
 """The bench line's schema (the driver's contract + roofline + cpu_baseline), checked on the committed N=1 line of
-this round (profiles/r01_bench_n1.json) and on bench.py's argument defaults.  No GPU needed."""
+this round (profiles/r02_bench_n1.json) and on bench.py's argument defaults.  No GPU needed."""
 import json
 import subprocess
 import sys
@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
+    line = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -29,8 +29,31 @@ def test_committed_bench_line_has_the_contract_fields():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["unit"] == "Mrows/s" and cpu["sample"]
     assert line["parity_check"] is True
-    for name in ("sort_8bit", "sort_4bit", "groupby", "join", "pjoin_p1"):
+    for name in ("sort_8bit", "sort_4bit", "groupby", "join", "join_radix", "pjoin_p1"):
         assert name in line["dwarfs"], name
+    # round 2: provenance of the traffic figure, cold-source control, the second roofline of the join, engine checks
+    src = roof["traffic_source"]
+    assert src["file"] == "profiles/hbm_traffic.json" and src["measured_in_this_run"] is False and src["provenance"]["git_head"]
+    assert 0.97 <= line["cold_over_warm_time"] <= 1.03 and line["value_cold"] > 0
+    gather = line["dwarfs"]["join"]["roofline_gather"]
+    assert gather["bound"] == "random_gather" and 0 < gather["frac"] <= 1.0
+    checks = line["dwarfs"]["pjoin_p1"]["checks"]
+    assert checks["wrong_probe_rows"] == 0 and checks["exchange_conserved"] and checks["all_rows_delivered"]
+
+
+def test_headline_profile_recomputes_the_roofline_fractions():
+    """profiles/r02_headline.json (kernel trace split per BASELINE configuration): every fraction follows from the
+    spans and algorithmic bytes in the file itself, and the scan's agrees with the bench line within 3 %"""
+    head = json.loads((ROOT / "profiles" / "r02_headline.json").read_text())["configurations"]
+    for name in ("scan_2p28", "sort_2p24_8bit", "sort_2p24_4bit", "groupby_2p26_2p16", "join_build", "join_probe", "join_2p26"):
+        assert name in head, name
+    for name, c in head.items():
+        if "frac_of_8TBps_from_span" in c:
+            assert abs(c["frac_of_8TBps_from_span"] - c["algorithmic_bytes"] / (c["span_us_avg"] * 1e-6) / 8e12) < 1e-9
+    line = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
+    assert abs(head["scan_2p28"]["frac_of_8TBps_from_span"] / line["roofline"]["frac"] - 1) < 0.03
+    k = head["scan_2p28"]["kernels"]
+    assert any("scan_chunk_kernel" in n for n in k) and any("scan_move_kernel" in n for n in k)
 
 
 def test_bench_defaults_and_help():
