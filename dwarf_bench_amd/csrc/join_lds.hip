@@ -104,6 +104,76 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__
     if (s_hist[i]) atomicAdd(&counts_g[static_cast<size_t>(group) * k1 + i], static_cast<unsigned long long>(s_hist[i]));
 }
 
+// ---- both levels' histograms in ONE read of the keys (parts <= 32768: the counters fit 128 KiB of LDS) --------------
+// Workgroup (group g, w) counts the FINAL partition of every row of its share of group g in an LDS histogram of `parts`
+// bins and stores it, plainly, as its own row of wgcnt[][]; jl_hist_reduce sums the rows: per (group, level-0 bucket)
+// for the level-0 cursors and per partition for level 1.  Replaces jl_hist0 + jl_hist1: the second used to re-read the
+// level-0 output (8 bytes per row: 113 us of the 2^26-row build).
+constexpr unsigned kJlFusedWgPerGroup = 4;   // 64 groups x 4 = 256 workgroups of 1024 threads: one per CU
+constexpr unsigned kJlFusedThreads = 1024;
+#ifndef DBHIP_JL_FUSED_MAX_PARTS
+#define DBHIP_JL_FUSED_MAX_PARTS 32768
+#endif
+constexpr unsigned kJlFusedMaxParts = DBHIP_JL_FUSED_MAX_PARTS;  // 0 disables the fused histogram (A/B timing)
+
+__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const unsigned *__restrict__ keys, size_t n,
+                                                                        unsigned parts, unsigned *__restrict__ wgcnt) {
+  extern __shared__ unsigned s_hist[];
+  const unsigned group = blockIdx.x / kJlFusedWgPerGroup, w = blockIdx.x % kJlFusedWgPerGroup;
+  for (unsigned i = threadIdx.x; i < parts; i += kJlFusedThreads) s_hist[i] = 0;
+  __syncthreads();
+  const size_t tpg = jl_tiles_per_group(n);
+  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
+  size_t hi = lo + tpg * kJlTile;
+  hi = hi < n ? hi : n;
+  for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < hi;
+       i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {  // four independent loads per lane per step
+    unsigned k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlFusedThreads < hi ? keys[i + j * kJlFusedThreads] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j * kJlFusedThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts)], 1u);
+  }
+  __syncthreads();
+  unsigned *mine = wgcnt + static_cast<size_t>(blockIdx.x) * parts;
+  for (unsigned i = threadIdx.x; i < parts; i += kJlFusedThreads) mine[i] = s_hist[i];
+}
+
+// counts1[p] = rows of partition p (column sums of wgcnt, one thread per partition: the first parts/256 workgroups),
+// counts0g[g][b] = rows of group g in level-0 bucket b (one WAVE per (workgroup row, bucket): k2 contiguous counters,
+// added to the zeroed counts0g with one atomic per wave: the remaining workgroups)
+__global__ __launch_bounds__(256) void jl_hist_reduce_kernel(const unsigned *__restrict__ wgcnt, unsigned parts, unsigned k1,
+                                                             unsigned k2, unsigned long long *counts0g,
+                                                             unsigned long long *counts1) {
+  constexpr unsigned kRows = kJlGroups * kJlFusedWgPerGroup;
+  const unsigned col_blocks = (parts + 255) / 256;
+  if (blockIdx.x < col_blocks) {
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= parts) return;
+    unsigned long long sum = 0;
+    for (unsigned r0 = 0; r0 < kRows; r0 += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wgcnt[static_cast<size_t>(r0 + u) * parts + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    counts1[p] = sum;
+    return;
+  }
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const size_t item = static_cast<size_t>(blockIdx.x - col_blocks) * 4 + wave;  // (row, bucket)
+  if (item >= static_cast<size_t>(kRows) * k1) return;
+  const unsigned row = static_cast<unsigned>(item / k1), bucket = static_cast<unsigned>(item % k1);
+  const unsigned *src = wgcnt + static_cast<size_t>(row) * parts + static_cast<size_t>(bucket) * k2;
+  unsigned mine = 0;
+  for (unsigned sub = lane; sub < k2; sub += kWave) mine += src[sub];
+  mine = wave_reduce_add(mine);
+  if (lane == kWave - 1 && mine)
+    atomicAdd(&counts0g[static_cast<size_t>(row / kJlFusedWgPerGroup) * k1 + bucket], static_cast<unsigned long long>(mine));
+}
+
 // bucket starts, per-group cursors and the tile index of every bucket (for the 1-D grid of level 1).
 // One workgroup, thread b owns bucket b (k1 <= 1024).
 __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long long *__restrict__ counts_g,
@@ -556,9 +626,12 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     //    (measured with the output stores compiled out: 400 of its 550 us at 2^26 rows), so a row costs two of them,
     //    not three: a plain read of the slot first (a duplicate of an already published key and every step of a
     //    collision chain need no ds_cmpst), ds_cmpst only on a slot read as empty, and ONE returning ds_add whose
-    //    old value is the row's rank — the fill then needs no second atomic.  (Advancing all rows of a lane together,
-    //    one probe step per round with their reads and ds_cmpst in flight at once, measured 35 % SLOWER: 1583 vs
-    //    1186 us for the 2^26 build.)
+    //    old value is the row's rank — the fill then needs no second atomic.  Two attempts at overlapping the LDS round
+    //    trips of a lane's rows both measured SLOWER: a loop of rounds (every row one probe step per round: 1583 vs 1186 us
+    //    for the 2^26 build) and a staged form (all first reads, then all first ds_cmpst, stragglers one by one, then all
+    //    rank atomics: 1194 vs 1110 us; the fused match kernel 940 vs 870 us) — in-kernel stamps put this phase at a
+    //    median 3500 of a 6500-cycle partition step with a 12000-cycle 90th percentile: the CU's LDS pipeline, shared
+    //    by four workgroups of random-address traffic, is what the rows queue on, not their own dependency chain.
     unsigned c_slot[kJlCached], c_rid[kJlCached], c_rank[kJlCached];
 #pragma unroll
     for (int r = 0; r < kJlCached; ++r) {
@@ -941,14 +1014,32 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
 
   const hipError_t e = fill_async(meta, 0, meta_bytes, s);
   if (e != hipSuccess) return static_cast<int>(e);
+  // scratch of the fused histogram: 256 rows of `parts` counters, in the level-1 output region while it is still unused
+  // (it holds 8n bytes; 1 KiB per partition is enough whenever a partition averages >= 128 rows)
+  unsigned *fused_scratch = (k2 > 1 && n * 8 >= static_cast<size_t>(kJlGroups) * kJlFusedWgPerGroup * parts * sizeof(unsigned))
+                                ? reinterpret_cast<unsigned *>(rows_b) : nullptr;
 
   // both levels write (key, row id) as ONE 8-byte element: a run of r rows is 8r contiguous bytes instead of two
   // runs of 4r (the scatters are bound by partially written lines: level 1 went 330 -> 254 us at 2^26 rows when it
   // switched, level 0 followed once the level-1 histogram read pairs instead of a keys-only column)
   const unsigned k2_shift = log2_k2;
   const size_t lds0 = jl_scatter_lds_bytes(k1);
-  hipLaunchKernelGGL(jl_hist0_kernel<false>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
-                     k1 * sizeof(unsigned), s, keys, n, parts, k2_shift, k1, counts0);
+  // two levels and at most 32768 partitions: both histograms from one read of the keys (wgcnt scratch: the level-1
+  // output region, written only later by the level-1 scatter)
+  // (8192..32768 partitions = 2^24..2^26 rows: level below it the two plain histograms are as fast, 2^22 rows: 77 vs 80 us)
+  const bool fused = k2 > 1 && parts >= 8192 && parts <= kJlFusedMaxParts && fused_scratch != nullptr;
+  if (fused) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_hist_fused_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(parts * sizeof(unsigned)));
+    if (ea != hipSuccess) return static_cast<int>(ea);
+    hipLaunchKernelGGL(jl_hist_fused_kernel, dim3(kJlGroups * kJlFusedWgPerGroup), dim3(kJlFusedThreads),
+                       parts * sizeof(unsigned), s, keys, n, parts, fused_scratch);
+    const unsigned red_grid = (parts + 255) / 256 + (kJlGroups * kJlFusedWgPerGroup * k1 + 3) / 4;
+    hipLaunchKernelGGL(jl_hist_reduce_kernel, dim3(red_grid), dim3(256), 0, s, fused_scratch, parts, k1, k2, counts0, counts1);
+  } else {
+    hipLaunchKernelGGL(jl_hist0_kernel<false>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
+                       k1 * sizeof(unsigned), s, keys, n, parts, k2_shift, k1, counts0);
+  }
   hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, cursors0, starts0, tstarts0,
                      static_cast<unsigned long long *>(nullptr));
   {
@@ -963,8 +1054,9 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   if (k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + k1);
     const size_t lds1 = jl_scatter_lds_bytes(k2);
-    hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
-                       rows_a, starts0, parts, k2, counts1);
+    if (!fused)
+      hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
+                         rows_a, starts0, parts, k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,
                        cursors1);
     // (one tile per workgroup; a persistent grid with the next tile's rows prefetched — what helps the level-0
