@@ -61,10 +61,10 @@ CONFIGS = {
     "sort_2p24_8bit": (r"rs_\w+<8|rs_finalize", r"rs_histogram_kernel<8", r"rs_finalize_kernel"),
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
     "groupby_2p26_2p16": (r"gb_aggregate_kernel|gb_reduce_kernel", r"gb_aggregate_kernel", r"gb_reduce_kernel"),
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_hist0_kernel", r"jl_build_kernel<false>"),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_build_kernel<false>"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
     # the radix join: both sides through the partitioner, then the fused build + probe launch
-    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>", r"jl_hist0_kernel", r"jl_build_kernel<true>"),
+    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_build_kernel<true>"),
 }
 
 
