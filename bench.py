@@ -5,16 +5,21 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM.
 N = 1 (default): the configuration BASELINE.json's metric is quoted on — TwoPassScan (stream compaction
-x < 5 over int32 uniform in [1, 10000]) at 2^28 rows.  The other single-GPU configurations of BASELINE.json
-(radix sort 2^24, group-by 2^26 rows / 2^16 groups, hash join 2^26 x 2^26) are measured in the same run with
-a few steps each and reported under "dwarfs" (they are not the headline value).
+x < 5 over int32 uniform in [1, 10000]) at 2^28 rows, with a cold-source control (`value_cold`: the same steps over
+five 1 GiB copies in rotation).  The other single-GPU configurations of BASELINE.json (radix sort 2^24, group-by 2^26
+rows / 2^16 groups, hash join 2^26 x 2^26 — row-ordered probe and radix join) and the 2^30 x 2^30 join on one GPU
+(`pjoin_p1`, the P = 1 point of the partitioned join) are measured in the same run with a few steps each and reported
+under "dwarfs" (they are not the headline value).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the headline stays the same metric — scan does not
 shard ("replicas only"), so every rank runs the 2^28 scan on its own GPU and `value` is the aggregate (weak
 scaling) — and the one part of the path that does shard, the radix-partitioned hash join 2^30 x 2^30 with its
-RCCL all-to-all, is measured in the same run (strong scaling) and reported under "pjoin" together with its
-single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.
-Rehearsal knobs (not for reported numbers): DBENCH_BACKEND=gloo lets several ranks share one GPU,
-DBENCH_PJOIN_LOG2 shrinks the partitioned join.
+RCCL all-to-all, is measured in the same run (strong scaling) and reported under "pjoin": on the C++ engine of the
+PartitionedJoinHip dwarf (libdbench.so, one rank per process, RCCL called from C++; device-side checks of the
+exchange and of the result in the warm-up) and, under "pjoin.torch_distributed_host", on the torch.distributed host —
+each with its single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.  A
+watchdog (DBENCH_PJOIN_DEADLINE_S, default 900 s) prints the line without a leg that hangs.
+Rehearsal knobs (not for reported numbers): DBENCH_BACKEND=gloo lets several ranks share one GPU (the C++ RCCL leg
+is skipped), DBENCH_PJOIN_LOG2 shrinks the partitioned join.
 
 Prints ONE JSON line on rank 0 with the contract fields plus "roofline" and "cpu_baseline".
 The oracle (oracle/) is used ONLY for the cpu_baseline leg and a one-off result check; the timed path is

@@ -68,10 +68,9 @@ class DevBuf {
       hip_ok(hipMemcpy(h.data(), p_, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
       return h;
     }
-    struct Pinned {
-      void *p = nullptr;
+    struct Pinned {  // lives until the process ends: freeing it from a static destructor would call into a HIP runtime
+      void *p = nullptr;  // that may already be shutting down
       size_t cap = 0;
-      ~Pinned() { (void)hipHostFree(p); }
     };
     static Pinned stage;
     constexpr size_t kChunk = static_cast<size_t>(64) << 20;
