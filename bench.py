@@ -366,15 +366,23 @@ class _Watchdog:
 
 
 def scan_selectivity_sweep(src, plan, n):
-    """SURVEY 8(d)'s secondary sweep: filter in {101, 1001, 5001} (selectivity ~1 %, 10 %, 50 %), 9 iterations each,
-    the reference notebook's drop-max-mean; algorithmic bytes 4*n*(1+s)."""
+    """SURVEY 8(d)'s secondary sweep: filter in {101, 1001, 5001, 10001} (selectivity ~1 %, 10 %, 50 %, 100 %), 9
+    iterations each, the reference notebook's drop-max-mean; algorithmic bytes 4*n*(1+s).  Both entry points are timed
+    (dbhip_copy_if_lt_i32: two launches through a staging buffer; dbhip_copy_if_lt_dense_i32: one launch, final
+    positions at first write); `kernel_us` is the one a plan picks by itself from the selectivity of its previous
+    call (ops.CopyIfLt.DENSE_ABOVE), named in `variant`."""
     out = {}
-    for filt in (101, 1001, 5001):
-        run = lambda: plan.launch(src, filt)
-        run()
-        us = _drop_max_mean(_event_times_us(run, 9))
+    for filt in (101, 1001, 5001, 10001):
+        t = {}
+        for name, dense in (("two_launch", False), ("dense", True)):
+            run = lambda: plan.launch(src, filt, dense=dense)
+            run()
+            t[name] = _drop_max_mean(_event_times_us(run, 9))
         m = plan.result().numel()
-        out[str(filt)] = {"selectivity": m / n, "kernel_us": us, "mrows_per_s": n / us,
+        variant = "dense" if m / n > plan.DENSE_ABOVE else "two_launch"
+        us = t[variant]
+        out[str(filt)] = {"selectivity": m / n, "variant": variant, "kernel_us": us, "two_launch_us": t["two_launch"],
+                          "dense_us": t["dense"], "mrows_per_s": n / us,
                           "frac_of_hbm_peak": (4 * n + 4 * m) / us / 1e3 / HBM_PEAK_GBS}
     return out
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "dbhip_gen_unique_sorted_u32": (_int, [_vp, _sz, _u64, _u64, _vp]),
     "dbhip_copy_if_lt_i32_workspace_bytes": (_sz, [_sz]),
     "dbhip_copy_if_lt_i32": (_int, [_vp, _sz, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "dbhip_copy_if_lt_dense_i32": (_int, [_vp, _sz, _i32, _vp, _vp, _vp, _sz, _vp]),
     "dbhip_radix_sort_workspace_bytes": (_sz, [_sz, _int]),
     "dbhip_radix_sort_u32": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp]),
     "dbhip_radix_sort_i32": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp]),

@@ -25,8 +25,10 @@ constexpr int kScanVpt = 8;                           // 16-byte loads per lane 
 constexpr int kScanWaveElems = kWave * kScanVpt * 4;  // 2048 contiguous elements per wave
 
 struct ScanWs {
-  unsigned status;  // DBHIP_DEV_* bits (this dwarf has no device-side failure: always DBHIP_DEV_OK after a call)
-  unsigned pad[63];
+  unsigned status;  // DBHIP_DEV_* bits (the two-launch path has no device-side failure; the dense path can time out)
+  unsigned pad0;
+  unsigned long long ticket;  // dense path: next chunk to hand out
+  unsigned pad[60];
 };
 static_assert(sizeof(ScanWs) == kWsHeader, "workspace header size");
 
@@ -83,6 +85,68 @@ __device__ __forceinline__ void emit_wave_matches(const i32x4 (&v)[kScanVpt], in
     row_base += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) +
                 __builtin_popcountll(b3);
   }
+}
+
+// ---- emission through LDS (dense path) --------------------------------------------------------------------------
+// Straight from the registers a tile costs up to 32 dword stores per lane whose lanes land one match-count apart: at
+// dense selectivities every instruction touches ~16 partial lines and the store path, not HBM, sets the pace (s = 1:
+// 2.8 TB/s of writes).  The dense path packs the matches of four rows (4 KiB per wave) into a wave-private LDS strip
+// at the destination's alignment (strip index = destination index mod 4); every full 16-byte group then leaves with
+// one aligned x4 store (1 KiB contiguous per wave instruction), the at most 3 + 3 edge elements go one by one.
+// Packing is branch-free: a lane without a match in a component writes that component to its own trash word (one
+// ds_write per component for the whole wave, no exec juggling) — the masked form costs ~100 instructions per row,
+// as long as the row's share of the stream; this one ~45.  (Straight to global memory the masked form stays the
+// right one: a dummy store would be HBM traffic.)
+constexpr int kStripRows = 4;
+constexpr int kStripTrash = kWave * kStripRows * 4 + 8;  // first of the 64 per-lane trash words
+constexpr int kStageStride = kStripTrash + kWave;        // ints per wave strip; a multiple of 4: strips stay 16-byte aligned
+
+__device__ __forceinline__ unsigned mbcnt_acc(unsigned long long mask, unsigned acc) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), acc));
+}
+
+// matches of rows [K0, K1) of v, in source order, to strip_rows[0 .. count); returns count
+template <int K0, int K1, int N>
+__device__ __forceinline__ unsigned emit_wave_rows_lds(const i32x4 (&v)[N], int filter, int *strip_rows, int *trash) {
+  unsigned row_base = 0;
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const bool m0 = v[k].x < filter, m1 = v[k].y < filter, m2 = v[k].z < filter, m3 = v[k].w < filter;
+    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
+    if ((b0 | b1 | b2 | b3) == 0) continue;  // scalar branch
+    const unsigned a0 = mbcnt_acc(b3, mbcnt_acc(b2, mbcnt_acc(b1, mbcnt_acc(b0, row_base))));
+    const unsigned a1 = a0 + (m0 ? 1u : 0u), a2 = a1 + (m1 ? 1u : 0u), a3 = a2 + (m2 ? 1u : 0u);
+    *(m0 ? strip_rows + a0 : trash) = v[k].x;
+    *(m1 ? strip_rows + a1 : trash) = v[k].y;
+    *(m2 ? strip_rows + a2 : trash) = v[k].z;
+    *(m3 ? strip_rows + a3 : trash) = v[k].w;
+    row_base += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) +
+                __builtin_popcountll(b3);
+  }
+  return row_base;
+}
+
+// strip[shift .. shift + run) -> dst[0 .. run), where shift = (dst / 4 bytes) mod 4.  LDS executes a wave's operations
+// in order, so write -> read -> overwrite needs no barrier beyond the compiler fences.
+__device__ __forceinline__ void flush_strip(const int *strip, unsigned shift, unsigned run, int *dst, unsigned lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int *g0 = dst - shift;  // 16-byte aligned; strip[i] belongs at g0[i] for shift <= i < shift + run
+  const unsigned end = shift + run, first_full = (shift + 3u) >> 2, last_full = end >> 2;
+  for (unsigned g = first_full + lane; g < last_full; g += kWave)
+    __builtin_nontemporal_store(*reinterpret_cast<const i32x4 *>(strip + 4 * g), reinterpret_cast<i32x4 *>(g0 + 4 * g));
+  // edges: the part of group 0 in front of the first full group, and what follows the last full group (a run that
+  // ends inside group 0 has no second edge)
+  if (lane < 4u) {
+    if (lane >= shift && lane < end && lane < 4u * first_full) g0[lane] = strip[lane];
+  } else if (lane < 8u) {
+    const unsigned i = 4u * last_full + lane - 4u;
+    if (last_full >= first_full && i < end) g0[i] = strip[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the strip is rewritten next
+  __builtin_amdgcn_wave_barrier();
 }
 
 // =================================================================================================
@@ -227,6 +291,194 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
   }
 }
 
+
+// =================================================================================================
+// Dense predicates (dbhip_copy_if_lt_dense_i32): final positions at FIRST write, most of the input read ONCE.
+//
+// The two-launch path above moves 12 bytes per match (staging write, staging read, final write) and is bound by
+// exactly that once the predicate is dense (s = 0.5: ~500 us for 1.61 GB of algorithmic bytes).  Final positions at
+// first write need the number of matches in front of a chunk before the chunk's matches leave the CU, i.e. a
+// hand-off between workgroups, and a place for the chunk to wait meanwhile.  Here that place is the register file:
+//   * a 16-wave workgroup (one per CU) takes a 256 KiB chunk by ticket; every wave owns 16 contiguous rows (1 KiB
+//     each) of it.  The last 12 rows stay in registers (48 VGPRs) from the count to the emission; the first 4 rows
+//     are counted, dropped and requested again right before the hand-off, so that this second read (on-die: the
+//     lines were read microseconds ago) is what the CU has in flight while it waits.  Fabric bytes 5n + 4m.
+//   * hand-off: chunk-granular decoupled look-back over 8-byte {state, value} granules (agent-scope relaxed
+//     atomics), one wave, 64 granules per poll.  With one workgroup per CU 256 chunks are in flight and a hop costs
+//     ~3 us per 256 KiB chunk (~10 us of stream).
+//   * emission through the LDS strips above, 16-byte non-temporal stores at the final positions.
+// Chunks go by TICKET, taken when the workgroup starts on the chunk: a chunk's predecessors are then always held by
+// workgroups that are already running, so every wait terminates whatever else shares the GPU; waits are
+// time-bounded anyway (2 s: DBHIP_DEV_SPIN_TIMEOUT).
+// What was measured on the way (2^28 rows, s = 0.5 / s = 0.01, same box; DESIGN.md 4.1 has the table):
+//   chunk read twice (count pass, look-back, emit pass; 512 KiB chunks)         392 / 318 us — bound by 8n + 4m on the
+//                                                                               fabric: the second read is served on
+//                                                                               die but costs its full fabric time
+//   whole chunk in registers, 4-wave workgroups x 2 per CU, 192 KiB chunks      431 / 397 us — hops of 17-23 us: the
+//                                                                               more chunks in flight, the further back
+//                                                                               the nearest inclusive prefix
+//   this kernel with 8- / 4-wave workgroups (2 / 4 per CU)                      322 / 255, 349 / 302 us — same reason
+//   this kernel, ticket of the next chunk requested one chunk ahead             345 / 261 us — a reserved chunk that
+//                                                                               nobody loads yet stalls its successors
+//   this kernel                                                                 311-325 / 245-257 us
+// Slower than the two-launch path for sparse predicates (hand-off per chunk, a quarter of the input read twice):
+// callers choose — ops.CopyIfLt and the TwoPassScan dwarf switch on the selectivity of the previous call (> 0.1).
+// =================================================================================================
+constexpr unsigned long long kLbShift = 62, kLbAggregate = 1ull << kLbShift, kLbInclusive = 2ull << kLbShift,
+                             kLbValue = (1ull << kLbShift) - 1;
+constexpr unsigned long long kSpinLimitTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Whole-wave look-back: lane l inspects chunk-1-l, the window slides back 64 chunks at a time until a chunk with an
+// INCLUSIVE prefix is met.  Returns the exclusive prefix of `chunk` (same in all lanes); chunk >= 1.
+__device__ __forceinline__ unsigned long long dn_lookback(const unsigned long long *granules, size_t chunk, unsigned lane,
+                                                          unsigned *status) {
+  unsigned long long excl = 0;
+  long long window_end = static_cast<long long>(chunk) - 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (true) {
+    const long long idx = window_end - static_cast<long long>(lane);
+    const unsigned long long g = idx >= 0 ? ld_agent(granules + idx) : kLbInclusive;  // below 0: inclusive prefix 0
+    const unsigned state = static_cast<unsigned>(g >> kLbShift);
+    const unsigned long long inc = __ballot(state == 2u);
+    const unsigned long long invalid = __ballot(state == 0u);
+    const int first_inc = inc ? __builtin_ctzll(inc) : kWave;
+    const unsigned long long need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
+    if (invalid & need) {  // a predecessor inside the window has not published yet
+      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+        if (lane == 0) atomicOr(status, DBHIP_DEV_SPIN_TIMEOUT);
+        return excl;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    const unsigned long long mine = static_cast<int>(lane) <= first_inc ? (g & kLbValue) : 0ull;
+    excl += wave_reduce_add_u64(mine);
+    if (first_inc < kWave) return excl;
+    window_end -= kWave;
+  }
+}
+
+constexpr int kKpStream = 4, kKpKeep = 12, kKpRows = kKpStream + kKpKeep;  // rows of a wave read twice / kept
+constexpr int kKpWaveElems = kKpRows * kWave * 4;                           // contiguous elements per wave
+constexpr int kKpChunk = kChWaves * kKpWaveElems;                           // 65536 elements = 256 KiB
+static_assert(kKpStream % kStripRows == 0 && kKpKeep % kStripRows == 0, "rows are emitted four at a time");
+
+template <int N, bool kFast, bool kNontemporal>
+__device__ __forceinline__ void kp_load_rows(i32x4 (&v)[N], const int *__restrict__ src, size_t n, size_t first,
+                                             unsigned lane) {
+  if (kFast) {
+    const i32x4 *p = reinterpret_cast<const i32x4 *>(src + first) + lane;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = kNontemporal ? __builtin_nontemporal_load(p + k * kWave) : p[k * kWave];
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const size_t e = first + (static_cast<size_t>(k) * kWave + lane) * 4;
+      v[k].x = e + 0 < n ? src[e + 0] : INT_MAX;  // INT_MAX never satisfies x < filter
+      v[k].y = e + 1 < n ? src[e + 1] : INT_MAX;
+      v[k].z = e + 2 < n ? src[e + 2] : INT_MAX;
+      v[k].w = e + 3 < n ? src[e + 3] : INT_MAX;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ unsigned kp_count_rows(const i32x4 (&v)[N], int filter) {
+  unsigned total = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    total += __builtin_popcountll(__ballot(v[k].x < filter));
+    total += __builtin_popcountll(__ballot(v[k].y < filter));
+    total += __builtin_popcountll(__ballot(v[k].z < filter));
+    total += __builtin_popcountll(__ballot(v[k].w < filter));
+  }
+  return total;
+}
+// rows [4G, 4G + 4) of v -> dst; returns the position behind them
+template <int G, int N>
+__device__ __forceinline__ int *kp_emit_group(const i32x4 (&v)[N], int filter, int *dst, int *strip, unsigned lane) {
+  const unsigned shift = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst) >> 2) & 3u;
+  const unsigned r = emit_wave_rows_lds<G * kStripRows, (G + 1) * kStripRows, N>(v, filter, strip + shift,
+                                                                                  strip + kStripTrash + lane);
+  if (r != 0) flush_strip(strip, shift, r, dst, lane);
+  return dst + r;
+}
+template <int N>
+__device__ __forceinline__ void kp_emit_rows(const i32x4 (&v)[N], int filter, int *dst, int *strip, unsigned lane) {
+  static_assert(N == 4 || N == 8 || N == 12, "groups of four rows");
+  dst = kp_emit_group<0, N>(v, filter, dst, strip, lane);
+  if (N >= 8) dst = kp_emit_group<(N >= 8 ? 1 : 0), N>(v, filter, dst, strip, lane);
+  if (N >= 12) dst = kp_emit_group<(N >= 12 ? 2 : 0), N>(v, filter, dst, strip, lane);
+}
+
+template <bool kAligned>
+__global__ __launch_bounds__(kChThreads) void scan_dense_kernel(const int *__restrict__ src, size_t n, int filter,
+                                                                int *__restrict__ out,
+                                                                unsigned long long *__restrict__ out_size, ScanWs *ws,
+                                                                unsigned long long *granules, size_t num_chunks) {
+  __shared__ unsigned s_cnt[kChWaves];
+  __shared__ unsigned long long s_chunk, s_excl;
+  __shared__ __attribute__((aligned(16))) int s_strip[kChWaves][kStageStride];
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  int *strip = s_strip[wave];
+  while (true) {
+    __syncthreads();  // s_chunk / s_cnt / s_excl of the previous chunk are no longer read
+    if (threadIdx.x == 0) s_chunk = __hip_atomic_fetch_add(&ws->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const size_t chunk = s_chunk;
+    if (chunk >= num_chunks) return;  // uniform
+    const size_t first = chunk * kKpChunk + static_cast<size_t>(wave) * kKpWaveElems;
+    const bool fast = kAligned && first + kKpWaveElems <= n;  // one decision for the wave's whole slice
+    i32x4 st[kKpStream], kp[kKpKeep];
+    unsigned c_st, c_kp;
+    if (fast) {
+      kp_load_rows<kKpStream, true, false>(st, src, n, first, lane);  // plain: read again below
+      kp_load_rows<kKpKeep, true, true>(kp, src, n, first + kKpStream * kWave * 4, lane);
+      c_st = kp_count_rows(st, filter);
+      if (c_st != 0) kp_load_rows<kKpStream, true, true>(st, src, n, first, lane);  // in flight across the hand-off
+      c_kp = kp_count_rows(kp, filter);
+    } else {  // the last chunk, or a source that is not 16-byte aligned: bounds-checked, everything stays in registers
+      kp_load_rows<kKpStream, false, false>(st, src, n, first, lane);
+      kp_load_rows<kKpKeep, false, false>(kp, src, n, first + kKpStream * kWave * 4, lane);
+      c_st = kp_count_rows(st, filter);
+      c_kp = kp_count_rows(kp, filter);
+    }
+    if (lane == 0) s_cnt[wave] = c_st + c_kp;
+    wg_barrier_lds_only();  // NOT __syncthreads(): its vmcnt(0) would wait for the second read
+    unsigned wave_excl = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kChWaves; ++w) {
+      const unsigned c = s_cnt[w];
+      wave_excl += w < static_cast<int>(wave) ? c : 0u;
+      total += c;
+    }
+    if (wave == 0) {  // publish the aggregate, look back, publish the inclusive prefix
+      unsigned long long excl = 0;
+      if (chunk == 0) {
+        if (lane == 0) st_agent(granules, kLbInclusive | total);
+      } else {
+        if (lane == 0) st_agent(granules + chunk, kLbAggregate | total);
+        excl = dn_lookback(granules, chunk, lane, &ws->status);
+        if (lane == 0) st_agent(granules + chunk, kLbInclusive | ((excl + total) & kLbValue));
+      }
+      if (lane == 0) {
+        s_excl = excl;
+        if (chunk == num_chunks - 1) *out_size = excl + total;
+      }
+    }
+    wg_barrier_lds_only();
+    int *dst = out + s_excl + wave_excl;
+    if (c_kp != 0) kp_emit_rows(kp, filter, dst + c_st, strip, lane);  // the kept rows first: st may still be landing
+    if (c_st != 0) kp_emit_rows(st, filter, dst, strip, lane);
+  }
+}
+
 inline int env_int(const char *name, int lo, int hi, int dflt) {
   const char *e = getenv(name);
   if (!e) return dflt;
@@ -283,4 +535,40 @@ extern "C" int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter
   if (!aligned) return launch_chunked<false, false>(src, n, filter_value, out, osz, workspace, dev, s);
   if (scan_nontemporal()) return launch_chunked<true, true>(src, n, filter_value, out, osz, workspace, dev, s);
   return launch_chunked<true, false>(src, n, filter_value, out, osz, workspace, dev, s);
+}
+
+// Dense predicates: one launch (+ the fill that zeroes ticket and granules), chunk-granular hand-off (see above).
+// Same arguments, same results and the same workspace size as dbhip_copy_if_lt_i32.
+extern "C" int dbhip_copy_if_lt_dense_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,
+                                          uint64_t *out_size, void *workspace, size_t workspace_bytes,
+                                          dbhip_stream_t stream) {
+  if (!out_size || (n && (!src || !out))) return DBHIP_EINVAL;
+  if (n >= (1ull << 61)) return DBHIP_EINVAL;
+  if (!ws_ok(workspace, workspace_bytes, dbhip_copy_if_lt_i32_workspace_bytes(n))) return DBHIP_EWORKSPACE;
+  const DeviceInfo &dev = current_device_info();
+  if (!dev.ok) return DBHIP_ENODEVICE;
+  hipStream_t s = as_stream(stream);
+  const size_t chunks = (n + kKpChunk - 1) / kKpChunk;
+  // granules live in the staging area of the two-launch path (n * 4 bytes: far more than 8 bytes per 256 KiB chunk)
+  const ChunkLayout L = chunk_layout(n ? n : 1);
+  char *base = static_cast<char *>(workspace);
+  unsigned long long *granules = reinterpret_cast<unsigned long long *>(base + L.staging_off);
+  hipError_t e = fill_async(workspace, 0, kWsHeader, s);
+  if (e == hipSuccess && n == 0) e = fill_async(out_size, 0, sizeof(uint64_t), s);
+  if (e != hipSuccess || n == 0) return static_cast<int>(e);
+  if (L.staging_off + chunks * sizeof(unsigned long long) > L.total) return DBHIP_EWORKSPACE;
+  e = fill_async(granules, 0, chunks * sizeof(unsigned long long), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+  unsigned long long *osz = reinterpret_cast<unsigned long long *>(out_size);
+  ScanWs *hdr = reinterpret_cast<ScanWs *>(base);
+  // one workgroup per CU: more chunks in flight only lengthen the look-back (see the table above)
+  const unsigned grid = static_cast<unsigned>(chunks < static_cast<size_t>(dev.cus) ? chunks : dev.cus);
+  if (aligned)
+    hipLaunchKernelGGL(scan_dense_kernel<true>, dim3(grid), dim3(kChThreads), 0, s, src, n, filter_value, out, osz, hdr,
+                       granules, chunks);
+  else
+    hipLaunchKernelGGL(scan_dense_kernel<false>, dim3(grid), dim3(kChThreads), 0, s, src, n, filter_value, out, osz, hdr,
+                       granules, chunks);
+  return launch_status();
 }

@@ -177,7 +177,10 @@ DwarfParams size_param(size_t n) { return DwarfParams{{"buf_size", std::to_strin
 void run_scan(const char *who, size_t n, Meter &meter) {
   const RunOptions &opts = meter.opts();
   banner(who);
-  const int filter_value = 5;  // scan/scan.cpp:73, scan/dplscan.cpp:43
+  // scan/scan.cpp:73, scan/dplscan.cpp:43 hard-code 5 (selectivity 4e-4 on keys 1..10000); DWARF_BENCH_SCAN_FILTER
+  // overrides it for the selectivity sweep of SURVEY 8(d)
+  const char *filter_env = std::getenv("DWARF_BENCH_SCAN_FILTER");
+  const int filter_value = filter_env ? std::atoi(filter_env) : 5;
   DevBuf<int32_t> src(n), out(n);
   DevBuf<uint64_t> out_size(1);
   const size_t ws_bytes = dbhip_copy_if_lt_i32_workspace_bytes(n);
@@ -194,7 +197,7 @@ void run_scan(const char *who, size_t n, Meter &meter) {
   if (host_check) {  // scan/scan.cpp:12-17 expected_out_lt
     const std::vector<int32_t> host = src.to_host(n);
     std::copy_if(host.begin(), host.end(), std::back_inserter(expected),
-                 [](int v) { return v < filter_value; });
+                 [filter_value](int v) { return v < filter_value; });
   } else {  // order-sensitive fingerprint + length of the matching subsequence, straight from src
     db_ok(dbhip_check_fingerprint_lt_i32(src.get(), n, filter_value, want.dev(), fp_ws.get(), fp_bytes, nullptr),
           "dbhip_check_fingerprint_lt_i32");
@@ -208,14 +211,20 @@ void run_scan(const char *who, size_t n, Meter &meter) {
     host_out.resize(n);
   }
   Events ev;
+  bool dense = false;
   for (size_t it = 0; it < opts.iterations; ++it) {
     auto result = std::make_unique<Result>();
     const auto host_start = clk::now();
     if (time_transfers() && n)
       hip_ok(hipMemcpy(src.get(), host_src.data(), n * sizeof(int32_t), hipMemcpyHostToDevice), "src H2D");
     hip_ok(hipEventRecord(ev.a, nullptr), "event");
-    db_ok(dbhip_copy_if_lt_i32(src.get(), n, filter_value, out.get(), out_size.get(), ws.get(), ws_bytes, nullptr),
-          "dbhip_copy_if_lt_i32");
+    // dense predicates (more than a tenth of the rows matched in the previous iteration) take the single-launch variant
+    if (dense)
+      db_ok(dbhip_copy_if_lt_dense_i32(src.get(), n, filter_value, out.get(), out_size.get(), ws.get(), ws_bytes,
+                                       nullptr), "dbhip_copy_if_lt_dense_i32");
+    else
+      db_ok(dbhip_copy_if_lt_i32(src.get(), n, filter_value, out.get(), out_size.get(), ws.get(), ws_bytes, nullptr),
+            "dbhip_copy_if_lt_i32");
     hip_ok(hipEventRecord(ev.b, nullptr), "event");
     if (time_transfers() && n)
       hip_ok(hipMemcpy(host_out.data(), out.get(), n * sizeof(int32_t), hipMemcpyDeviceToHost), "out D2H");
@@ -226,6 +235,7 @@ void run_scan(const char *who, size_t n, Meter &meter) {
     result->kernel_time = ev.elapsed();
     result->bytes = n * sizeof(int32_t) + count * sizeof(int32_t);
     check_status(ws.get(), who);
+    dense = n && count > n / 10;
     if (inject_fault() && count) poke_xor(out.get() + count / 2, 1u);
     bool ok;
     if (host_check) {

@@ -56,6 +56,7 @@ extern "C" {
 
 /* device-side status word values (dbhip_workspace_status) */
 #define DBHIP_DEV_OK 0u
+#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* dbhip_copy_if_lt_dense_i32: a chunk waited 2 s for its predecessors (never seen) */
 #define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count, or the 0xFFFFFFFF sentinel as a join build key */
 #define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
 
@@ -91,6 +92,16 @@ size_t dbhip_copy_if_lt_i32_workspace_bytes(size_t n);
 int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,
                          uint64_t *out_size, void *workspace, size_t workspace_bytes,
                          dbhip_stream_t stream);
+
+/* The same compaction for DENSE predicates (more than about a tenth of the rows match): one launch, every match
+ * written once at its final position (HBM bytes 4n + 4*out_size instead of 4n + 12*out_size).  A workgroup keeps
+ * three quarters of its 256 KiB chunk in registers while it waits for the number of matches in front of the chunk
+ * and reads the remaining quarter a second time (on-die) during that wait.  Chunks are taken by ticket, so every
+ * wait is on a workgroup that is already running; waits are bounded (DBHIP_DEV_SPIN_TIMEOUT).
+ * Same arguments, results and workspace size as dbhip_copy_if_lt_i32; slower than it for sparse predicates.        */
+int dbhip_copy_if_lt_dense_i32(const int32_t *src, size_t n, int32_t filter_value, int32_t *out,
+                               uint64_t *out_size, void *workspace, size_t workspace_bytes,
+                               dbhip_stream_t stream);
 
 /* ---- dwarf 2: LSD radix sort ---------------------------------------------------------------
  * Ascending sort of n 32-bit keys.  keys is sorted IN PLACE; tmp is an n-element ping-pong buffer.

@@ -137,6 +137,22 @@ def test_fault_injection_flips_valid(dwarf, extra, limit):
     assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
 
 
+@pytest.mark.parametrize("filt", ["1001", "5001", "10001"])
+def test_scan_dwarf_dense_predicates(filt):
+    """DWARF_BENCH_SCAN_FILTER moves the scan dwarfs off the reference's filter value 5: from the second iteration on a
+    dense predicate runs dbhip_copy_if_lt_dense_i32; every iteration is validated (host check at 2^20, device-side
+    fingerprint at 2^28)"""
+    import os
+    env = {**os.environ, "DWARF_BENCH_SCAN_FILTER": filt}
+    r = _run(["TwoPassScanHip", "--device=hip", "--iterations", "4", "--input_size", "1048576", "268435456"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 8
+    env["DWARF_BENCH_INJECT_FAULT"] = "1"
+    r = _run(["DPLScanHip", "--device=hip", "--iterations", "3", "--input_size", "268435456"], env=env)
+    assert r.returncode == 0 and r.stderr.count("ncorrect results") == 3, r.stderr
+
+
 def test_probe_dwarf_over_the_bitmask_table():
     """ProbeHip (probe/slab_probe.cpp:9-107) over the SimpleNonOwningHashTable counterpart"""
     import os

@@ -122,3 +122,68 @@ def test_beyond_32_bit_byte_offsets(log2n, extra, filt):
         assert torch.equal(got[off: off + want.numel()], want), lo
         off += want.numel()
     assert off == got.numel()
+
+
+# ---- dense variant (dbhip_copy_if_lt_dense_i32): one launch, chunk-granular hand-off, final positions at first write;
+# a wave owns 4096 elements of a 65536-element chunk: sizes around both ----
+@pytest.mark.parametrize("n", [0, 1, 3, 64, 4095, 4096, 4097, 8191, 32768, 32769, 65535, 65536, 65537, 131072, 131073,
+                               524288, 524289, 1 << 20, (1 << 22) + 12345, (1 << 25) + 7])
+@pytest.mark.parametrize("filt", [5, 5001, 20000, -3])
+def test_dense_copy_if_matches_oracle(n, filt):
+    from dwarf_bench_amd import ops
+    src = _src(n)
+    got = ops.copy_if_lt(src, filt, dense=True).cpu().numpy()
+    exp = po.copy_if_lt(src.cpu().numpy(), filt)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_dense_variant_unaligned_extremes_and_plan_switch():
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(2)
+    host = rng.integers(-2**31, 2**31 - 1, 700001, dtype=np.int64).astype(np.int32)
+    host[::97] = np.iinfo(np.int32).min
+    host[1::89] = np.iinfo(np.int32).max
+    base = torch.from_numpy(host).cuda()
+    for off in (0, 1, 3):
+        src = base[off:]
+        for filt in (np.iinfo(np.int32).min, 0, np.iinfo(np.int32).max):
+            got = ops.copy_if_lt(src, int(filt), dense=True).cpu().numpy()
+            assert np.array_equal(got, po.copy_if_lt(host[off:], int(filt)))
+    # a plan picks the variant from the selectivity it saw last for that filter value; results never differ
+    n = 1 << 22
+    src = _src(n)
+    plan = ops.CopyIfLt(n)
+    exp_dense, exp_sparse = po.copy_if_lt(src.cpu().numpy(), 5001), po.copy_if_lt(src.cpu().numpy(), 5)
+    for _ in range(3):
+        plan.launch(src, 5001)  # first call: two-launch path; then the dense one (selectivity 0.5)
+        assert np.array_equal(plan.result().cpu().numpy(), exp_dense)
+        plan.launch(src, 5)     # stays on the two-launch path (selectivity 4e-4)
+        assert np.array_equal(plan.result().cpu().numpy(), exp_sparse)
+    assert plan._seen[5001] > plan.DENSE_ABOVE > plan._seen[5]
+
+
+def test_dense_variant_at_full_size_and_on_concurrent_streams():
+    """2^28 rows at 50 % selectivity against the two-launch path (fingerprint + length), and four dense scans in flight
+    on four streams: chunks are taken by ticket, so a chunk's predecessors always belong to running workgroups"""
+    from dwarf_bench_amd import ops
+    n = 1 << 28
+    src = _src(n)
+    a = ops.CopyIfLt(n)
+    a.launch(src, 5001, dense=True)
+    out = a.result()
+    want = ops.check_fingerprint_lt(src, 5001)
+    assert want[1] == out.numel() and ops.check_fingerprint_lt(out, 5001) == want
+    del a, out
+    m = 1 << 24
+    small = src[:m]
+    plans = [ops.CopyIfLt(m) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for p, st in zip(plans, streams):
+            with torch.cuda.stream(st):
+                p.launch(small, 5001, dense=True)
+    torch.cuda.synchronize()
+    exp = ops.copy_if_lt(small, 5001)
+    for p in plans:
+        assert torch.equal(p.result(), exp)
