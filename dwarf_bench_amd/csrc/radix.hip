@@ -26,6 +26,10 @@
 // Bytes: 4N (histogram) + P * 12N (chunk histogram read + scatter read/write), P <= 32/BITS; at 2^24
 // keys both ping-pong buffers (128 MiB) live in the 256 MiB Infinity Cache.  Everything between passes
 // stays device-side (skipped passes return at once on a device-side flag, no host round trip).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "dbhip_common.hpp"
 
 namespace dbhip {
@@ -303,11 +307,79 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   }
 }
 
+// ---- ranking by LDS atomics: the property it rests on, checked on the device before it is used --------------------
+// rank = atomicAdd(&count[wave][digit], 1) replaces the BITS ballots of match_digit (8-bit digits: ~55 of the scatter's
+// ~100 vector instructions per 64 keys; the kernel is VALU-bound) by one ds_add_rtn_u32.  An LSD sort needs a STABLE
+// rank.  Between instructions the LDS keeps a wave's operations in issue order; INSIDE one instruction the rank is
+// stable iff lanes that hit the same counter get their return values in ascending lane order.  gfx950 does that (the
+// LDS serialises the lanes of a conflicting access lowest lane first) but the ISA manual does not promise it, so the
+// first sort on a device runs this kernel — every lane compares what the atomic returned with the count the ballots
+// predict, over dense, sparse, skewed and partially masked digit patterns on every CU — and the sort only ranks by
+// atomics where no lane ever disagreed; otherwise it keeps the ballots (DBHIP_RS_RANK=ballot|atomic overrides).
+__global__ __launch_bounds__(kRsThreads) void rs_rank_selftest_kernel(unsigned *mismatches) {
+  __shared__ unsigned s_cnt[kRsWaves][256];
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  for (int i = tid; i < kRsWaves * 256; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+  __syncthreads();
+  unsigned bad = 0;
+  for (unsigned it = 0; it < 512; ++it) {
+    unsigned h = (blockIdx.x * 977u + wave * 131u + it) * 0x9E3779B1u + lane * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    const unsigned spread = it & 7u;  // 0: one counter for the whole wave ... 7: 256 counters
+    const unsigned d = spread == 0 ? (it >> 3) & 255u : (h >> 8) & ((2u << spread) - 1u);
+    const bool valid = (it & 8u) == 0 || (h & 3u) != 0;  // every other group of 8: a quarter of the lanes masked off
+    LaneMask m = match_digit<8>(d);
+    const unsigned long long v = __ballot(valid);
+    m.lo &= static_cast<unsigned>(v);
+    m.hi &= static_cast<unsigned>(v >> 32);
+    const unsigned expect = s_cnt[wave][d] + lanes_before(m);
+    if (valid) {
+      const unsigned got = atomicAdd(&s_cnt[wave][d], 1u);
+      bad += got != expect;
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+// true: the scatter may rank by LDS atomics on the current device.  Decided once per device (a launch and a stream
+// synchronisation on the caller's stream, inside the first sort); while the stream is being captured into a graph
+// and nothing is known yet, the answer is "ballots" and nothing is cached.  scratch: one device word.
+std::atomic<int> g_rank_verdict[64];  // per device: 0 unknown, 1 atomics, 2 ballots
+int rank_forced() {
+  static const int forced = [] {
+    const char *e = std::getenv("DBHIP_RS_RANK");
+    return !e ? 0 : (std::strcmp(e, "atomic") == 0 ? 1 : (std::strcmp(e, "ballot") == 0 ? 2 : 0));
+  }();
+  return forced;
+}
+bool rank_by_lds_atomics(hipStream_t s, unsigned *scratch) {
+  std::atomic<int> *verdict = g_rank_verdict;
+  const int forced = rank_forced();
+  if (forced) return forced == 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const int known = verdict[dev].load(std::memory_order_acquire);
+  if (known) return known == 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+  unsigned host = 1;
+  const DeviceInfo &info = current_device_info();
+  if (fill_async(scratch, 0, sizeof(unsigned), s) != hipSuccess) return false;
+  hipLaunchKernelGGL(rs_rank_selftest_kernel, dim3(info.ok ? info.cus * 2 : 512), dim3(kRsThreads), 0, s, scratch);
+  if (hipMemcpyAsync(&host, scratch, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return false;
+  verdict[dev].store(host == 0 ? 1 : 2, std::memory_order_release);
+  return host == 0;
+}
+
 // ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
 // One tile of the scatter: stable rank inside each wave, digit offsets across waves, re-order through LDS, write out
 // in digit order.  FULL = the tile holds kRsTile keys: no per-key bounds checks (the kernel is VALU-bound — about 100
 // vector instructions per 64 keys, 80 % of the issue slots at 2^24 keys by the SQ counters).
-template <int BITS, bool FULL>
+template <int BITS, bool FULL, bool ARANK>
 __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src, unsigned *__restrict__ dst,
                                                 size_t tile_base, unsigned valid_in_tile, int shift, unsigned xor_mask,
                                                 unsigned &running, unsigned (*s_cnt)[1 << BITS], unsigned *s_dexcl,
@@ -330,6 +402,10 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
   for (int j = 0; j < kRsKpt; ++j) {
     const bool valid = FULL || wave_first + j * kWave < valid_in_tile;
     const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+    if (ARANK) {  // one returning LDS atomic: see rank_by_lds_atomics() for why this is a stable rank
+      rank[j] = valid ? atomicAdd(&s_cnt[wave][d], 1u) : 0u;
+      continue;
+    }
     LaneMask m = match_digit<BITS>(d);
     if (!FULL) {
       const unsigned long long v = __ballot(valid);
@@ -388,7 +464,7 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
   __syncthreads();
 }
 
-template <int BITS>
+template <int BITS, bool ARANK>
 __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
                                                                          int pass, unsigned xor_mask,
                                                                          const RsHeader *hdr,
@@ -443,10 +519,10 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
     const size_t tile_base = tile * kRsTile;
     const unsigned valid_in_tile = static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
     if (valid_in_tile == kRsTile)  // every tile but the input's last one
-      rs_scatter_tile<BITS, true>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
+      rs_scatter_tile<BITS, true, ARANK>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
                                   s_wsum, s_keys);
     else
-      rs_scatter_tile<BITS, false>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
+      rs_scatter_tile<BITS, false, ARANK>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
                                    s_wsum, s_keys);
   }
 }
@@ -456,7 +532,7 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
 // are all that is measured).  Keys stay in registers between passes; every pass ranks them exactly as the
 // scatter kernel does and re-orders them through LDS; passes whose digit is constant over the input are skipped
 // on a workgroup-uniform vote; the result is written back to `keys`.
-template <int BITS>
+template <int BITS, bool ARANK>
 __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kernel(unsigned *keys, unsigned n,
                                                                                   unsigned xor_mask) {
   constexpr int kRadix = 1 << BITS;
@@ -500,6 +576,10 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
     for (int j = 0; j < kRsKpt; ++j) {
       const bool valid = wave_first + j * kWave < n;
       const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      if (ARANK) {
+        rank[j] = valid ? atomicAdd(&s_cnt[wave][d], 1u) : 0u;
+        continue;
+      }
       LaneMask m = match_digit<BITS>(d);
       const unsigned long long v = __ballot(valid);
       m.lo &= static_cast<unsigned>(v);
@@ -573,11 +653,16 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
   unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
 
+  const bool arank = rank_by_lds_atomics(s, totals);  // (totals is cleared below)
   if (n <= static_cast<size_t>(kRsTile)) {  // one tile: one workgroup, one launch (+ the status word)
     const hipError_t e0 = fill_async(workspace, 0, kWsHeader, s);
     if (e0 != hipSuccess) return static_cast<int>(e0);
-    hipLaunchKernelGGL((rs_single_tile_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, keys, static_cast<unsigned>(n),
-                       xor_mask);
+    if (arank)
+      hipLaunchKernelGGL((rs_single_tile_kernel<BITS, true>), dim3(1), dim3(kRsThreads), 0, s, keys,
+                         static_cast<unsigned>(n), xor_mask);
+    else
+      hipLaunchKernelGGL((rs_single_tile_kernel<BITS, false>), dim3(1), dim3(kRsThreads), 0, s, keys,
+                         static_cast<unsigned>(n), xor_mask);
     return launch_status();
   }
   hipError_t e = fill_async(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
@@ -599,9 +684,13 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
     if (!fused_scan)
       hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
                          g.chunks);
-    hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys, tmp, n, p,
-                       xor_mask, hdr, counts, fused_scan ? bases : static_cast<const unsigned *>(nullptr), g.tiles_per_chunk,
-                       g.chunks);
+    const unsigned *fused_bases = fused_scan ? bases : static_cast<const unsigned *>(nullptr);
+    if (arank)
+      hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, true>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys,
+                         tmp, n, p, xor_mask, hdr, counts, fused_bases, g.tiles_per_chunk, g.chunks);
+    else
+      hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, false>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys,
+                         tmp, n, p, xor_mask, hdr, counts, fused_bases, g.tiles_per_chunk, g.chunks);
   }
   hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
   return launch_status();
@@ -637,6 +726,14 @@ extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
   const RsGeometry g = rs_geometry(n);
   const size_t radix = static_cast<size_t>(1) << radix_bits;
   return align_up(kRsCountsOff + sizeof(unsigned) * radix * g.chunks, kWsAlign);
+}
+
+extern "C" int dbhip_radix_sort_rank_mode(void) {
+  if (rank_forced()) return rank_forced() == 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  const int v = g_rank_verdict[dev].load(std::memory_order_acquire);
+  return v == 0 ? -1 : (v == 1 ? 1 : 0);
 }
 
 extern "C" int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits,

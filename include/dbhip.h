@@ -114,6 +114,10 @@ int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits
 /* signed order (the reference sorts `int`, sort/radix.cpp:8-12) */
 int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
+/* How the scatter ranks keys on the current device: 1 = one returning LDS atomic per key (used only where the
+ * device-side self-test of the first sort saw same-address lanes served in lane order: gfx950 does), 0 = ballots,
+ * -1 = not decided yet (no sort has run outside a graph capture).  DBHIP_RS_RANK=ballot|atomic overrides.        */
+int dbhip_radix_sort_rank_mode(void);
 
 /* ---- dwarf 3: group-by hash aggregate, SUM ------------------------------------------------------
  * out[g] = sum of vals[i] over rows with keys[i] == g (uint32 wrap-around), g in [0, groups).

@@ -108,3 +108,28 @@ def test_empty_input_and_unaligned_column():
     keys = ops.gen_uniform_u32(1001, 1, 0, 2**32 - 1)
     with pytest.raises(ValueError, match="16-byte"):
         ops.radix_sort_(keys[1:])
+
+
+def test_rank_by_lds_atomics_is_self_checked_and_both_rankings_agree():
+    """The scatter ranks with one returning LDS atomic per key where the device passed the lane-order self-test of its
+    first sort (gfx950 does); DBHIP_RS_RANK=ballot keeps the ballot ranking: both give the oracle's order, at sizes
+    on every path (single tile, fused scan, chunked) and both digit widths."""
+    import os, subprocess, sys
+    from dwarf_bench_amd import _capi, ops
+    keys = ops.gen_uniform_u32(1 << 20, 3, 0, 2**32 - 1)
+    ops.radix_sort_(keys, signed=False, radix_bits=8)
+    assert _capi.lib().dbhip_radix_sort_rank_mode() == 1
+    prog = (
+        "import numpy as np, torch\n"
+        "from dwarf_bench_amd import _capi, ops\n"
+        "from oracle import pyoracle as po\n"
+        "for n in (100, 8192, 8193, 200000, (1 << 22) + 77):\n"
+        "    for bits in (8, 4):\n"
+        "        k = ops.gen_uniform_u32(n, 11, 0, 2**32 - 1); h = k.cpu().numpy().view(np.uint32)\n"
+        "        ops.radix_sort_(k, signed=False, radix_bits=bits)\n"
+        "        assert np.array_equal(k.cpu().numpy().view(np.uint32), po.sort_u32(h)), (n, bits)\n"
+        "print('mode', _capi.lib().dbhip_radix_sort_rank_mode())\n")
+    for mode, want in (("ballot", "mode 0"), ("atomic", "mode 1")):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300,
+                           env={**os.environ, "DBHIP_RS_RANK": mode}, cwd=os.path.dirname(os.path.dirname(__file__)))
+        assert r.returncode == 0 and want in r.stdout, (mode, r.stdout, r.stderr)
