@@ -87,10 +87,12 @@ constexpr size_t kRsCountsOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * 
 struct RsGeometry {
   size_t tiles, tiles_per_chunk, chunks;
 };
-inline RsGeometry rs_geometry(size_t n) {
+inline RsGeometry rs_geometry(size_t n, int bits) {
   RsGeometry g;
+  // 4-bit digits: half as many, twice as long chunks (2^24 keys: 378 -> 363 us; 8-bit digits: no difference)
+  const size_t target = bits == 4 ? kRsTargetChunks / 2 : kRsTargetChunks;
   g.tiles = (n + kRsTile - 1) / kRsTile;
-  g.tiles_per_chunk = (g.tiles + kRsTargetChunks - 1) / kRsTargetChunks;
+  g.tiles_per_chunk = (g.tiles + target - 1) / target;
   if (g.tiles_per_chunk == 0) g.tiles_per_chunk = 1;
   g.chunks = (g.tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
   if (g.chunks == 0) g.chunks = 1;
@@ -646,7 +648,7 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
                     hipStream_t s, const DeviceInfo &dev) {
   constexpr int kPasses = 32 / BITS;
   constexpr int kRadix = 1 << BITS;
-  const RsGeometry g = rs_geometry(n);
+  const RsGeometry g = rs_geometry(n, BITS);
   char *base = static_cast<char *>(workspace);
   RsHeader *hdr = reinterpret_cast<RsHeader *>(base);
   unsigned *totals = reinterpret_cast<unsigned *>(base + kRsTotalsOff);
@@ -723,7 +725,7 @@ using namespace dbhip;
 
 extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
   if (radix_bits != 4 && radix_bits != 8) return 0;
-  const RsGeometry g = rs_geometry(n);
+  const RsGeometry g = rs_geometry(n, radix_bits);
   const size_t radix = static_cast<size_t>(1) << radix_bits;
   return align_up(kRsCountsOff + sizeof(unsigned) * radix * g.chunks, kWsAlign);
 }
