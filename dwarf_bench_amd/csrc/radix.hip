@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_rank_selftest_kernel(unsigned *
   for (int i = tid; i < kRsWaves * 256; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
   unsigned bad = 0;
-  for (unsigned it = 0; it < 512; ++it) {
+  for (unsigned it = 0; it < 128; ++it) {
     unsigned h = (blockIdx.x * 977u + wave * 131u + it) * 0x9E3779B1u + lane * 0x85EBCA6Bu;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
@@ -369,7 +369,7 @@ bool rank_by_lds_atomics(hipStream_t s, unsigned *scratch) {
   unsigned host = 1;
   const DeviceInfo &info = current_device_info();
   if (fill_async(scratch, 0, sizeof(unsigned), s) != hipSuccess) return false;
-  hipLaunchKernelGGL(rs_rank_selftest_kernel, dim3(info.ok ? info.cus * 2 : 512), dim3(kRsThreads), 0, s, scratch);
+  hipLaunchKernelGGL(rs_rank_selftest_kernel, dim3(info.ok ? info.cus * 2 : 512), dim3(kRsThreads), 0, s, scratch);  // ~50 us, once
   if (hipMemcpyAsync(&host, scratch, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return false;
