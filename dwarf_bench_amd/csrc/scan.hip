@@ -299,13 +299,12 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
 // exactly that once the predicate is dense (s = 0.5: ~500 us for 1.61 GB of algorithmic bytes).  Final positions at
 // first write need the number of matches in front of a chunk before the chunk's matches leave the CU, i.e. a
 // hand-off between workgroups, and a place for the chunk to wait meanwhile.  Here that place is the register file:
-//   * a 16-wave workgroup (one per CU) takes a 256 KiB chunk by ticket; every wave owns 16 contiguous rows (1 KiB
+//   * an 8-wave workgroup (two per CU) takes a 128 KiB chunk by ticket; every wave owns 16 contiguous rows (1 KiB
 //     each) of it.  The last 12 rows stay in registers (48 VGPRs) from the count to the emission; the first 4 rows
 //     are counted, dropped and requested again right before the hand-off, so that this second read (on-die: the
-//     lines were read microseconds ago) is what the CU has in flight while it waits.  Fabric bytes 5n + 4m.
+//     lines were read microseconds ago) is what the wave has in flight while it waits.  Fabric bytes 5n + 4m.
 //   * hand-off: chunk-granular decoupled look-back over 8-byte {state, value} granules (agent-scope relaxed
-//     atomics), one wave, 64 granules per poll.  With one workgroup per CU 256 chunks are in flight and a hop costs
-//     ~3 us per 256 KiB chunk (~10 us of stream).
+//     atomics), one wave, 64 granules per poll, every granule on a 128-byte line of its own.
 //   * emission through the LDS strips above, 16-byte non-temporal stores at the final positions.
 // Chunks go by TICKET, taken when the workgroup starts on the chunk: a chunk's predecessors are then always held by
 // workgroups that are already running, so every wait terminates whatever else shares the GPU; waits are
@@ -314,19 +313,20 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
 //   chunk read twice (count pass, look-back, emit pass; 512 KiB chunks)         392 / 318 us — bound by 8n + 4m on the
 //                                                                               fabric: the second read is served on
 //                                                                               die but costs its full fabric time
-//   whole chunk in registers, 4-wave workgroups x 2 per CU, 192 KiB chunks      431 / 397 us — hops of 17-23 us: the
-//                                                                               more chunks in flight, the further back
-//                                                                               the nearest inclusive prefix
-//   this kernel with 8- / 4-wave workgroups (2 / 4 per CU)                      322 / 255, 349 / 302 us — same reason
-//   this kernel, ticket of the next chunk requested one chunk ahead             345 / 261 us — a reserved chunk that
+//   whole chunk in registers, 4-wave workgroups x 2 per CU, 192 KiB chunks      431 / 397 us — hops of 17-23 us
+//   packed granules (eight per line): 16- / 8- / 4-wave workgroups              311-325 / 245-257, 322 / 255, 349 / 302 us
+//   ... ticket of the next chunk requested one chunk ahead                      345 / 261 us — a reserved chunk that
 //                                                                               nobody loads yet stalls its successors
-//   this kernel                                                                 311-325 / 245-257 us
+//   ... 256 granules per poll                                                   342 / 274 us
+//   one granule per line: 16- / 8- (this kernel) / 4-wave workgroups            316-318 / 250, 300 / 239, 334 / 320 us
 // Slower than the two-launch path for sparse predicates (hand-off per chunk, a quarter of the input read twice):
 // callers choose — ops.CopyIfLt and the TwoPassScan dwarf switch on the selectivity of the previous call (> 0.1).
 // =================================================================================================
 constexpr unsigned long long kLbShift = 62, kLbAggregate = 1ull << kLbShift, kLbInclusive = 2ull << kLbShift,
                              kLbValue = (1ull << kLbShift) - 1;
 constexpr unsigned long long kSpinLimitTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
+constexpr size_t kGranuleStride = 16;  // in granules: every chunk's granule has a 128-byte line of its own (packed
+                                       // granules: the line a poll reads is being written by eight other chunks)
 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -344,7 +344,7 @@ __device__ __forceinline__ unsigned long long dn_lookback(const unsigned long lo
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (true) {
     const long long idx = window_end - static_cast<long long>(lane);
-    const unsigned long long g = idx >= 0 ? ld_agent(granules + idx) : kLbInclusive;  // below 0: inclusive prefix 0
+    const unsigned long long g = idx >= 0 ? ld_agent(granules + idx * kGranuleStride) : kLbInclusive;  // below 0: inclusive prefix 0
     const unsigned state = static_cast<unsigned>(g >> kLbShift);
     const unsigned long long inc = __ballot(state == 2u);
     const unsigned long long invalid = __ballot(state == 0u);
@@ -367,7 +367,8 @@ __device__ __forceinline__ unsigned long long dn_lookback(const unsigned long lo
 
 constexpr int kKpStream = 4, kKpKeep = 12, kKpRows = kKpStream + kKpKeep;  // rows of a wave read twice / kept
 constexpr int kKpWaveElems = kKpRows * kWave * 4;                           // contiguous elements per wave
-constexpr int kKpChunk = kChWaves * kKpWaveElems;                           // 65536 elements = 256 KiB
+constexpr int kKpWaves = 8;                                                 // two workgroups per CU
+constexpr int kKpChunk = kKpWaves * kKpWaveElems;                           // 32768 elements = 128 KiB
 static_assert(kKpStream % kStripRows == 0 && kKpKeep % kStripRows == 0, "rows are emitted four at a time");
 
 template <int N, bool kFast, bool kNontemporal>
@@ -418,13 +419,13 @@ __device__ __forceinline__ void kp_emit_rows(const i32x4 (&v)[N], int filter, in
 }
 
 template <bool kAligned>
-__global__ __launch_bounds__(kChThreads) void scan_dense_kernel(const int *__restrict__ src, size_t n, int filter,
+__global__ __launch_bounds__(kKpWaves * kWave) void scan_dense_kernel(const int *__restrict__ src, size_t n, int filter,
                                                                 int *__restrict__ out,
                                                                 unsigned long long *__restrict__ out_size, ScanWs *ws,
                                                                 unsigned long long *granules, size_t num_chunks) {
-  __shared__ unsigned s_cnt[kChWaves];
+  __shared__ unsigned s_cnt[kKpWaves];
   __shared__ unsigned long long s_chunk, s_excl;
-  __shared__ __attribute__((aligned(16))) int s_strip[kChWaves][kStageStride];
+  __shared__ __attribute__((aligned(16))) int s_strip[kKpWaves][kStageStride];
   const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   int *strip = s_strip[wave];
   while (true) {
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kChThreads) void scan_dense_kernel(const int *__res
     wg_barrier_lds_only();  // NOT __syncthreads(): its vmcnt(0) would wait for the second read
     unsigned wave_excl = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kChWaves; ++w) {
+    for (int w = 0; w < kKpWaves; ++w) {
       const unsigned c = s_cnt[w];
       wave_excl += w < static_cast<int>(wave) ? c : 0u;
       total += c;
@@ -463,9 +464,9 @@ __global__ __launch_bounds__(kChThreads) void scan_dense_kernel(const int *__res
       if (chunk == 0) {
         if (lane == 0) st_agent(granules, kLbInclusive | total);
       } else {
-        if (lane == 0) st_agent(granules + chunk, kLbAggregate | total);
+        if (lane == 0) st_agent(granules + chunk * kGranuleStride, kLbAggregate | total);
         excl = dn_lookback(granules, chunk, lane, &ws->status);
-        if (lane == 0) st_agent(granules + chunk, kLbInclusive | ((excl + total) & kLbValue));
+        if (lane == 0) st_agent(granules + chunk * kGranuleStride, kLbInclusive | ((excl + total) & kLbValue));
       }
       if (lane == 0) {
         s_excl = excl;
@@ -549,26 +550,26 @@ extern "C" int dbhip_copy_if_lt_dense_i32(const int32_t *src, size_t n, int32_t 
   if (!dev.ok) return DBHIP_ENODEVICE;
   hipStream_t s = as_stream(stream);
   const size_t chunks = (n + kKpChunk - 1) / kKpChunk;
-  // granules live in the staging area of the two-launch path (n * 4 bytes: far more than 8 bytes per 256 KiB chunk)
+  // granules live in the staging area of the two-launch path (n * 4 bytes: far more than 128 bytes per 128 KiB chunk)
   const ChunkLayout L = chunk_layout(n ? n : 1);
   char *base = static_cast<char *>(workspace);
   unsigned long long *granules = reinterpret_cast<unsigned long long *>(base + L.staging_off);
   hipError_t e = fill_async(workspace, 0, kWsHeader, s);
   if (e == hipSuccess && n == 0) e = fill_async(out_size, 0, sizeof(uint64_t), s);
   if (e != hipSuccess || n == 0) return static_cast<int>(e);
-  if (L.staging_off + chunks * sizeof(unsigned long long) > L.total) return DBHIP_EWORKSPACE;
-  e = fill_async(granules, 0, chunks * sizeof(unsigned long long), s);
+  if (L.staging_off + chunks * kGranuleStride * sizeof(unsigned long long) > L.total) return DBHIP_EWORKSPACE;
+  e = fill_async(granules, 0, chunks * kGranuleStride * sizeof(unsigned long long), s);
   if (e != hipSuccess) return static_cast<int>(e);
   const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
   unsigned long long *osz = reinterpret_cast<unsigned long long *>(out_size);
   ScanWs *hdr = reinterpret_cast<ScanWs *>(base);
-  // one workgroup per CU: more chunks in flight only lengthen the look-back (see the table above)
-  const unsigned grid = static_cast<unsigned>(chunks < static_cast<size_t>(dev.cus) ? chunks : dev.cus);
+  const size_t cap = static_cast<size_t>(dev.cus) * (16 / kKpWaves);  // as many as fit: 16 waves per CU at 120 VGPRs
+  const unsigned grid = static_cast<unsigned>(chunks < cap ? chunks : cap);
   if (aligned)
-    hipLaunchKernelGGL(scan_dense_kernel<true>, dim3(grid), dim3(kChThreads), 0, s, src, n, filter_value, out, osz, hdr,
+    hipLaunchKernelGGL(scan_dense_kernel<true>, dim3(grid), dim3(kKpWaves * kWave), 0, s, src, n, filter_value, out, osz, hdr,
                        granules, chunks);
   else
-    hipLaunchKernelGGL(scan_dense_kernel<false>, dim3(grid), dim3(kChThreads), 0, s, src, n, filter_value, out, osz, hdr,
+    hipLaunchKernelGGL(scan_dense_kernel<false>, dim3(grid), dim3(kKpWaves * kWave), 0, s, src, n, filter_value, out, osz, hdr,
                        granules, chunks);
   return launch_status();
 }

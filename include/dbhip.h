@@ -95,7 +95,7 @@ int dbhip_copy_if_lt_i32(const int32_t *src, size_t n, int32_t filter_value, int
 
 /* The same compaction for DENSE predicates (more than about a tenth of the rows match): one launch, every match
  * written once at its final position (HBM bytes 4n + 4*out_size instead of 4n + 12*out_size).  A workgroup keeps
- * three quarters of its 256 KiB chunk in registers while it waits for the number of matches in front of the chunk
+ * three quarters of its 128 KiB chunk in registers while it waits for the number of matches in front of the chunk
  * and reads the remaining quarter a second time (on-die) during that wait.  Chunks are taken by ticket, so every
  * wait is on a workgroup that is already running; waits are bounded (DBHIP_DEV_SPIN_TIMEOUT).
  * Same arguments, results and workspace size as dbhip_copy_if_lt_i32; slower than it for sparse predicates.        */

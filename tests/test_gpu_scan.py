@@ -125,7 +125,7 @@ def test_beyond_32_bit_byte_offsets(log2n, extra, filt):
 
 
 # ---- dense variant (dbhip_copy_if_lt_dense_i32): one launch, chunk-granular hand-off, final positions at first write;
-# a wave owns 4096 elements of a 65536-element chunk: sizes around both ----
+# a wave owns 4096 elements of a 32768-element chunk: sizes around both ----
 @pytest.mark.parametrize("n", [0, 1, 3, 64, 4095, 4096, 4097, 8191, 32768, 32769, 65535, 65536, 65537, 131072, 131073,
                                524288, 524289, 1 << 20, (1 << 22) + 12345, (1 << 25) + 7])
 @pytest.mark.parametrize("filt", [5, 5001, 20000, -3])
