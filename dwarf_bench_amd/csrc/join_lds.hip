@@ -126,14 +126,35 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const un
   const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
   size_t hi = lo + tpg * kJlTile;
   hi = hi < n ? hi : n;
-  for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < hi;
-       i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {  // four independent loads per lane per step
-    unsigned k[4];
+  if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
+    // 16-byte loads, four in flight per lane (4-byte loads kept 16 KiB per CU in flight: 79 us for 256 MiB of keys)
+    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
+    const size_t n4 = (hi - lo) / 4;
+    for (size_t i = static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < n4;
+         i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {
+      u32x4 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) k[j] = i + j * kJlFusedThreads < hi ? keys[i + j * kJlFusedThreads] : 0u;
+      for (int j = 0; j < 4; ++j) v[j] = i + j * kJlFusedThreads < n4 ? k4[i + j * kJlFusedThreads] : u32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i + j * kJlFusedThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts)], 1u);
+      for (int j = 0; j < 4; ++j)
+        if (i + j * kJlFusedThreads < n4) {
+          atomicAdd(&s_hist[jl_pid(v[j].x, parts)], 1u);
+          atomicAdd(&s_hist[jl_pid(v[j].y, parts)], 1u);
+          atomicAdd(&s_hist[jl_pid(v[j].z, parts)], 1u);
+          atomicAdd(&s_hist[jl_pid(v[j].w, parts)], 1u);
+        }
+    }
+    if (w == 0 && lo + n4 * 4 + threadIdx.x < hi) atomicAdd(&s_hist[jl_pid(keys[lo + n4 * 4 + threadIdx.x], parts)], 1u);
+  } else {
+    for (size_t i = lo + static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < hi;
+         i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {  // four independent loads per lane per step
+      unsigned k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[j] = i + j * kJlFusedThreads < hi ? keys[i + j * kJlFusedThreads] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j * kJlFusedThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts)], 1u);
+    }
   }
   __syncthreads();
   unsigned *mine = wgcnt + static_cast<size_t>(blockIdx.x) * parts;
