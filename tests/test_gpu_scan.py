@@ -105,14 +105,16 @@ def test_stress_under_uneven_load(n):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("log2n,extra,filt", [(31, 5, 5), (30, 12345, 5001)])
-def test_beyond_32_bit_byte_offsets(log2n, extra, filt):
-    """n * 4 bytes > 4 GiB: 64-bit indexing everywhere (torch's boolean indexing as the independent check)"""
+@pytest.mark.parametrize("log2n,extra,filt,dense", [(31, 5, 5, False), (30, 12345, 5001, False), (31, 5, 5001, True),
+                                                    (30, 12345, 10001, True)])
+def test_beyond_32_bit_byte_offsets(log2n, extra, filt, dense):
+    """n * 4 bytes > 4 GiB: 64-bit indexing everywhere, both entry points (torch's boolean indexing as the independent
+    check)"""
     from dwarf_bench_amd import ops
     n = (1 << log2n) + extra
     src = ops.gen_uniform_u32(n, 77, 1, 10000)
     plan = ops.CopyIfLt(n)
-    plan.launch(src, filt)
+    plan.launch(src, filt, dense=dense)
     got = plan.result()
     # compare piecewise to bound the temporary memory of the torch reference
     step, off = 1 << 28, 0
