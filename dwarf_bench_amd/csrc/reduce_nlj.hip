@@ -10,6 +10,8 @@
 //
 // Both are HBM-bound: reduce reads 4 B/row once (nontemporal 16-B loads, 8 in flight per lane),
 // nested-loop join writes 12 B per cell.
+#include <cstdlib>
+
 #include "dbhip_common.hpp"
 
 namespace dbhip {
@@ -18,6 +20,10 @@ namespace {
 constexpr int kRedThreads = 512;
 constexpr int kRedVecsPerLane = 8;  // 8 x 16 B in flight per lane
 constexpr size_t kRedTileInts = static_cast<size_t>(kRedThreads) * kRedVecsPerLane * 4;  // 64 KiB tiles
+#ifndef DBHIP_RED_CHUNK_TILES
+#define DBHIP_RED_CHUNK_TILES 16
+#endif
+constexpr size_t kRedChunkTiles = DBHIP_RED_CHUNK_TILES;  // 1 MiB of consecutive tiles per workgroup turn
 
 __global__ __launch_bounds__(kRedThreads) void reduce_sum_kernel(const int *__restrict__ src, size_t n, unsigned head,
                                                                  unsigned *__restrict__ out) {
@@ -30,15 +36,32 @@ __global__ __launch_bounds__(kRedThreads) void reduce_sum_kernel(const int *__re
   n -= head;
   const size_t full_tiles = n / kRedTileInts;
   const i32x4 *vsrc = reinterpret_cast<const i32x4 *>(src);
-  for (size_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {
+  // A workgroup takes kRedChunkTiles consecutive tiles at a time (1 MiB of contiguous addresses, like the scan's
+  // chunks) and keeps the next tile's loads in flight while it adds the current one.
+  auto load_tile = [&](size_t t, i32x4 (&v)[kRedVecsPerLane]) {
     const i32x4 *p = vsrc + t * (kRedTileInts / 4) + threadIdx.x;
-    i32x4 v[kRedVecsPerLane];
 #pragma unroll
     for (int k = 0; k < kRedVecsPerLane; ++k) v[k] = __builtin_nontemporal_load(p + k * kRedThreads);
+  };
+  auto add_tile = [&](const i32x4 (&v)[kRedVecsPerLane]) {
 #pragma unroll
     for (int k = 0; k < kRedVecsPerLane; ++k)
       acc += static_cast<unsigned>(v[k].x) + static_cast<unsigned>(v[k].y) + static_cast<unsigned>(v[k].z) +
              static_cast<unsigned>(v[k].w);
+  };
+  const size_t chunks = (full_tiles + kRedChunkTiles - 1) / kRedChunkTiles;
+  for (size_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const size_t t0 = c * kRedChunkTiles;
+    const size_t t1 = t0 + kRedChunkTiles < full_tiles ? t0 + kRedChunkTiles : full_tiles;
+    i32x4 a[kRedVecsPerLane], b[kRedVecsPerLane];
+    load_tile(t0, a);
+    for (size_t t = t0; t < t1; t += 2) {
+      if (t + 1 < t1) load_tile(t + 1, b);
+      add_tile(a);
+      if (t + 1 >= t1) break;
+      if (t + 2 < t1) load_tile(t + 2, a);
+      add_tile(b);
+    }
   }
   // ragged tail (< one tile), shared by the grid
   const size_t tail0 = full_tiles * kRedTileInts;
@@ -96,8 +119,10 @@ extern "C" int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, 
   if (e != hipSuccess) return static_cast<int>(e);
   if (n == 0) return DBHIP_OK;
   const size_t tiles = (n + kRedTileInts - 1) / kRedTileInts;
-  const size_t cap = static_cast<size_t>(dev.cus) * 4;  // 4 x 512 threads per CU: full occupancy
-  const unsigned grid = static_cast<unsigned>(tiles < cap ? tiles : cap);
+  const size_t chunks = (tiles + kRedChunkTiles - 1) / kRedChunkTiles;
+  static const int wgs_per_cu = [] { const char *e = std::getenv("DBHIP_RED_WGS"); return e ? std::atoi(e) : 2; }();
+  const size_t cap = static_cast<size_t>(dev.cus) * wgs_per_cu;
+  const unsigned grid = static_cast<unsigned>(chunks < cap ? (chunks ? chunks : 1) : cap);
   size_t head = ((16 - (reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / 4;  // src is 4-byte aligned (int32)
   if (head > n) head = n;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid), dim3(kRedThreads), 0, s, src, n, static_cast<unsigned>(head),
