@@ -554,11 +554,15 @@ extern "C" int dbhip_copy_if_lt_dense_i32(const int32_t *src, size_t n, int32_t 
   const ChunkLayout L = chunk_layout(n ? n : 1);
   char *base = static_cast<char *>(workspace);
   unsigned long long *granules = reinterpret_cast<unsigned long long *>(base + L.staging_off);
-  hipError_t e = fill_async(workspace, 0, kWsHeader, s);
-  if (e == hipSuccess && n == 0) e = fill_async(out_size, 0, sizeof(uint64_t), s);
-  if (e != hipSuccess || n == 0) return static_cast<int>(e);
-  if (L.staging_off + chunks * kGranuleStride * sizeof(unsigned long long) > L.total) return DBHIP_EWORKSPACE;
-  e = fill_async(granules, 0, chunks * kGranuleStride * sizeof(unsigned long long), s);
+  if (n == 0) {
+    hipError_t e0 = fill_async(workspace, 0, kWsHeader, s);
+    if (e0 == hipSuccess) e0 = fill_async(out_size, 0, sizeof(uint64_t), s);
+    return static_cast<int>(e0);
+  }
+  const size_t granule_bytes = chunks * kGranuleStride * sizeof(unsigned long long);
+  if (L.staging_off + granule_bytes > L.total) return DBHIP_EWORKSPACE;
+  // one fill for the header (status, ticket), the unused chunk counts and the granules behind them
+  const hipError_t e = fill_async(workspace, 0, L.staging_off + granule_bytes, s);
   if (e != hipSuccess) return static_cast<int>(e);
   const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
   unsigned long long *osz = reinterpret_cast<unsigned long long *>(out_size);
