@@ -366,6 +366,8 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
       out_keys[slot] = k;
       out_rids[slot] = s_rids[p];
     } else {  // one array of (key, row id) pairs: one 8-byte store per row, a run of r rows is 8r contiguous bytes
+      // (plain stores: the runs of neighbouring tiles meet in L2; non-temporal stores here made a partition side of
+      //  2^26 rows 778 us instead of 602)
       reinterpret_cast<u32x2 *>(out_keys)[slot] = u32x2{k, s_rids[p]};
     }
   }
