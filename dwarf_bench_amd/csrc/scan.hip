@@ -10,8 +10,10 @@
 //     registers, counts, and writes its matches at an offset inside the chunk's staging slot.
 //   * In-wave ranks come from the compare masks themselves: v_cmp -> 64-bit ballot in SGPRs,
 //     s_bcnt1 for totals, v_mbcnt_lo/hi for the lane-exclusive prefix.
-//   * No workgroup ever waits on another one (see below): no tickets, no look-back, no spin, nothing to time
-//     out; every call is two launches whatever the size.
+//   * dbhip_copy_if_lt_i32: no workgroup ever waits on another one (see below): no tickets, no look-back, no
+//     spin, nothing to time out; every call is two launches whatever the size.
+//   * dbhip_copy_if_lt_dense_i32 (dense predicates, second half of this file): one launch, matches written once at
+//     their final positions; a chunk waits for the match count in front of it (ticketed chunks, bounded wait).
 //
 // Algorithmic HBM bytes: 4*n read + 4*out_size written.
 #include <climits>
