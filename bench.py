@@ -140,17 +140,19 @@ def bench_scan(steps, warmup, log2n=28, filt=5, cold=False):
     }
 
 
-def bench_sort(steps, warmup, log2n=24, bits=8):
+def bench_sort(steps, warmup, log2n=24, bits=8, reference_range=False):
+    """full-range uint32 keys (BASELINE config), or reference_range: the reference's own data — `int` keys uniform in
+    [1, 10000] (sort/radix.cpp:19), signed order; the two upper bytes are constant and their passes are skipped"""
     import torch
     from dwarf_bench_amd import ops
     n = 1 << log2n
-    keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    keys0 = ops.gen_uniform_u32(n, 42, 1, 10000) if reference_range else ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
     keys = keys0.clone()
     plan = ops.RadixSort(n, bits)
 
     def run():
         keys.copy_(keys0)  # every step sorts unsorted data (sort/radix.cpp:31)
-        plan.launch(keys)
+        plan.launch(keys, signed=reference_range)
 
     for _ in range(warmup):
         run()
@@ -163,7 +165,8 @@ def bench_sort(steps, warmup, log2n=24, bits=8):
             "compulsory_bytes": 8 * n, "pass_model_bytes": 4 * n + passes * 8 * n,
             "frac_of_hbm_peak_compulsory": 8 * n / us / 1e3 / HBM_PEAK_GBS,
             "frac_of_hbm_peak_pass_model": (4 * n + passes * 8 * n) / us / 1e3 / HBM_PEAK_GBS,
-            "workload": f"Radix sort 2^{log2n} uint32 full-range keys, {bits}-bit LSD digits"}
+            "workload": (f"Radix sort 2^{log2n} int32 keys in [1,10000] (reference data), {bits}-bit LSD digits"
+                         if reference_range else f"Radix sort 2^{log2n} uint32 full-range keys, {bits}-bit LSD digits")}
 
 
 def bench_groupby(steps, warmup, log2n=26, groups=1 << 16):
@@ -471,8 +474,8 @@ def main():
     ap.add_argument("--dwarf", default="all", choices=["all", "scan", "sort", "groupby", "join"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pjoin", action="store_true", help="skip the single-GPU 2^30 x 2^30 join (profiling passes)")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the scan selectivity sweep (counter passes: keeps "
-                    "every scan dispatch at the headline selectivity)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the scan selectivity sweep and the reference-range "
+                    "sorts (counter passes: keeps every scan / sort dispatch at the BASELINE configuration)")
     args = ap.parse_args()
 
     rank, world, local = _dist_env()
@@ -562,6 +565,9 @@ def main():
         if args.dwarf in ("all", "sort"):
             dwarfs["sort_8bit"] = bench_sort(k, 2, 24, 8)
             dwarfs["sort_4bit"] = bench_sort(k, 2, 24, 4)
+            if not args.no_sweep:  # (the profiler passes keep every sort dispatch at the BASELINE configuration)
+                dwarfs["sort_8bit_reference_range"] = bench_sort(k, 2, 24, 8, reference_range=True)
+                dwarfs["sort_4bit_reference_range"] = bench_sort(k, 2, 24, 4, reference_range=True)
         if args.dwarf in ("all", "groupby"):
             dwarfs["groupby"] = bench_groupby(k, 2)
         if args.dwarf in ("all", "join"):
