@@ -19,6 +19,7 @@
 #include <climits>
 
 #include "dbhip_common.hpp"
+#include "handoff.hpp"
 
 namespace dbhip {
 namespace {
@@ -324,49 +325,6 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
 // Slower than the two-launch path for sparse predicates (hand-off per chunk, a quarter of the input read twice):
 // callers choose — ops.CopyIfLt and the TwoPassScan dwarf switch on the selectivity of the previous call (> 0.1).
 // =================================================================================================
-constexpr unsigned long long kLbShift = 62, kLbAggregate = 1ull << kLbShift, kLbInclusive = 2ull << kLbShift,
-                             kLbValue = (1ull << kLbShift) - 1;
-constexpr unsigned long long kSpinLimitTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
-constexpr size_t kGranuleStride = 16;  // in granules: every chunk's granule has a 128-byte line of its own (packed
-                                       // granules: the line a poll reads is being written by eight other chunks)
-
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Whole-wave look-back: lane l inspects chunk-1-l, the window slides back 64 chunks at a time until a chunk with an
-// INCLUSIVE prefix is met.  Returns the exclusive prefix of `chunk` (same in all lanes); chunk >= 1.
-__device__ __forceinline__ unsigned long long dn_lookback(const unsigned long long *granules, size_t chunk, unsigned lane,
-                                                          unsigned *status) {
-  unsigned long long excl = 0;
-  long long window_end = static_cast<long long>(chunk) - 1;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (true) {
-    const long long idx = window_end - static_cast<long long>(lane);
-    const unsigned long long g = idx >= 0 ? ld_agent(granules + idx * kGranuleStride) : kLbInclusive;  // below 0: inclusive prefix 0
-    const unsigned state = static_cast<unsigned>(g >> kLbShift);
-    const unsigned long long inc = __ballot(state == 2u);
-    const unsigned long long invalid = __ballot(state == 0u);
-    const int first_inc = inc ? __builtin_ctzll(inc) : kWave;
-    const unsigned long long need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
-    if (invalid & need) {  // a predecessor inside the window has not published yet
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
-        if (lane == 0) atomicOr(status, DBHIP_DEV_SPIN_TIMEOUT);
-        return excl;
-      }
-      __builtin_amdgcn_s_sleep(2);
-      continue;
-    }
-    const unsigned long long mine = static_cast<int>(lane) <= first_inc ? (g & kLbValue) : 0ull;
-    excl += wave_reduce_add_u64(mine);
-    if (first_inc < kWave) return excl;
-    window_end -= kWave;
-  }
-}
-
 constexpr int kKpStream = 4, kKpKeep = 12, kKpRows = kKpStream + kKpKeep;  // rows of a wave read twice / kept
 constexpr int kKpWaveElems = kKpRows * kWave * 4;                           // contiguous elements per wave
 constexpr int kKpWaves = 8;                                                 // two workgroups per CU
@@ -462,14 +420,7 @@ __global__ __launch_bounds__(kKpWaves * kWave) void scan_dense_kernel(const int 
       total += c;
     }
     if (wave == 0) {  // publish the aggregate, look back, publish the inclusive prefix
-      unsigned long long excl = 0;
-      if (chunk == 0) {
-        if (lane == 0) st_agent(granules, kLbInclusive | total);
-      } else {
-        if (lane == 0) st_agent(granules + chunk * kGranuleStride, kLbAggregate | total);
-        excl = dn_lookback(granules, chunk, lane, &ws->status);
-        if (lane == 0) st_agent(granules + chunk * kGranuleStride, kLbInclusive | ((excl + total) & kLbValue));
-      }
+      const unsigned long long excl = chunk_handoff(granules, chunk, total, lane, &ws->status);
       if (lane == 0) {
         s_excl = excl;
         if (chunk == num_chunks - 1) *out_size = excl + total;
