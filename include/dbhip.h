@@ -252,7 +252,9 @@ int dbhip_nested_join_u32(const uint32_t *a_keys, const uint32_t *a_vals, const 
  * dst[0] = init, dst[i] = init + src[0] + ... + src[i-1], uint32 wrap-around: the semantics of the reference's
  * prefix_sum_scalar / prefix_local_test (tests/scan_tests.cpp:14-21, :46-51, scan/scan.cl:44-66) and of
  * oneDPL exclusive_scan behind DPLWrapper::exclusive_scan (common/dpcpp/dpl_wrapper/dpl_wrapper.hpp:18-25,
- * used by common/dpcpp/omnisci_hashtable.hpp:252-254).  dst may alias src.                             */
+ * used by common/dpcpp/omnisci_hashtable.hpp:252-254).  dst may alias src.
+ * 16-byte aligned src and dst: ONE launch, every element read once and written once (128 KiB chunks kept in registers
+ * across a ticketed chunk-to-chunk hand-off; bounded wait: DBHIP_DEV_SPIN_TIMEOUT); other alignments: three launches. */
 size_t dbhip_exclusive_scan_u32_workspace_bytes(size_t n);
 int dbhip_exclusive_scan_u32(const uint32_t *src, size_t n, uint32_t init, uint32_t *dst, void *workspace,
                              size_t workspace_bytes, dbhip_stream_t stream);
