@@ -31,7 +31,8 @@ def test_exclusive_scan_reference_kat(golden_dir):
     assert got.tolist() == kat["expected"] == [0, 0, 1, 2, 2, 2, 3]
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 4096, 100003, (1 << 22) + 5, (1 << 24) + 1027])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 32767, 32768, 32769, 65536, 100003,
+                               (1 << 22) + 5, (1 << 24) + 1027])
 def test_exclusive_scan_matches_oracle(n):
     from dwarf_bench_amd import ops
     src = ops.gen_uniform_u32(n, 3, 0, 0xFFFFFFFF if n % 2 else 10000)  # wrap-around sums on the odd sizes
@@ -55,6 +56,44 @@ def test_exclusive_scan_init_in_place_and_unaligned():
     assert np.array_equal(ops.exclusive_scan(src, init=77).cpu().numpy().view(np.uint32), exp)
     ops.exclusive_scan(src, init=77, out=src)
     assert np.array_equal(src.cpu().numpy().view(np.uint32), exp)
+
+
+def test_exclusive_scan_aligned_in_place_init_and_streams():
+    """the single-launch path (16-byte aligned columns): init, in place, and four scans in flight on four streams
+    (chunks go by ticket: a chunk's predecessors always belong to running workgroups)"""
+    from dwarf_bench_amd import ops
+    n = (1 << 23) + 77
+    src = ops.gen_uniform_u32(n, 9, 0, 0xFFFFFFFF)
+    host = src.cpu().numpy().view(np.uint32)
+    exp = np.zeros(n, dtype=np.uint32)
+    np.cumsum(host[:-1], dtype=np.uint32, out=exp[1:])
+    exp += np.uint32(123)
+    outs = [torch.empty_like(src) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for o, st in zip(outs, streams):
+            with torch.cuda.stream(st):
+                ops.exclusive_scan(src, init=123, out=o)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), exp)
+    work = src.clone()
+    ops.exclusive_scan(work, init=123, out=work)
+    assert np.array_equal(work.cpu().numpy().view(np.uint32), exp)
+
+
+def test_exclusive_scan_beyond_32_bit_byte_offsets():
+    from dwarf_bench_amd import ops
+    n = (1 << 30) + 5
+    src = ops.gen_uniform_u32(n, 4, 0, 3)
+    got = ops.exclusive_scan(src)
+    step, carry = 1 << 27, 0
+    for lo in range(0, n, step):
+        part = src[lo: lo + step].to(torch.int64)
+        incl = torch.cumsum(part, 0) + carry
+        assert torch.equal(got[lo: lo + step].to(torch.int64) & 0xFFFFFFFF, (incl - part) & 0xFFFFFFFF), lo
+        carry = int(incl[-1])
 
 
 def test_exclusive_scan_feeds_the_omnisci_positions():
