@@ -16,8 +16,10 @@ scaling) — and the one part of the path that does shard, the radix-partitioned
 RCCL all-to-all, is measured in the same run (strong scaling) and reported under "pjoin": on the C++ engine of the
 PartitionedJoinHip dwarf (libdbench.so, one rank per process, RCCL called from C++; device-side checks of the
 exchange and of the result in the warm-up) and, under "pjoin.torch_distributed_host", on the torch.distributed host —
-each with its single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.  A
-watchdog (DBENCH_PJOIN_DEADLINE_S, default 900 s) prints the line without a leg that hangs.
+each with its single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.  The
+section runs in CHILD processes (every rank starts `bench.py --pjoin-child`, own process group one port up): a leg that
+hangs is cut by a watchdog (DBENCH_PJOIN_DEADLINE_S, default 900 s), a leg that takes its process down (a GPU memory
+fault aborts the process) costs `pjoin` an `error` entry, never the contract line (tests/test_gpu_bench_launcher.py).
 Rehearsal knobs (not for reported numbers): DBENCH_BACKEND=gloo lets several ranks share one GPU (the C++ RCCL leg
 is skipped), DBENCH_PJOIN_LOG2 shrinks the partitioned join.
 
@@ -466,6 +468,103 @@ def cpu_baselines_dwarfs(which):
 
 
 # ---------------------------------------------------------------------------------------------------
+def pjoin_section(args, dist, rank, world, local, barrier, out):
+    """The one part of the hot path that shards (BASELINE north_star): the hash join, radix-partitioned across the
+    ranks with an RCCL all-to-all bucket exchange.  STRONG scaling: 2^30 x 2^30 in total whatever N is.  Two hosts
+    drive the same device kernels and are both reported: the C++ engine of the PartitionedJoinHip dwarf (`pjoin`, the
+    headline of this section) and the torch.distributed one (`pjoin.torch_distributed_host`).  Each one's single-GPU
+    reference point is measured in this same run, on rank 0's GPU, while the other ranks wait — so the speed-ups are
+    self-contained in the line.  Fills out["pjoin"] on rank 0."""
+    import torch
+    n_gpus = world
+    torch.cuda.empty_cache()
+    pj_steps, pj_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+    pj_log2 = int(os.environ.get("DBENCH_PJOIN_LOG2", "30"))
+    dog = _Watchdog(int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")), rank, out)
+    section = {"metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
+               "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm}
+    if rank == 0:
+        out["pjoin"] = section
+    try:
+        dog.leg = "torch.distributed host, all ranks"
+        pj = bench_pjoin(pj_steps, pj_warm, pj_log2, dist)
+        torch.cuda.empty_cache()
+        dog.leg = "torch.distributed host, one GPU"
+        solo = dist.new_group(ranks=[0])  # collective call; only rank 0 uses it: its join below is purely local
+        p1 = bench_pjoin(2, 1, pj_log2, None, group=solo) if rank == 0 else None
+        barrier()
+        torch.cuda.empty_cache()
+        if rank == 0:
+            section["torch_distributed_host"] = {
+                "parallelism": f"hash-partitioned over {n_gpus} ranks, all_to_all bucket exchange (RCCL over xGMI) "
+                               "overlapped with partition/build, local LDS-partitioned join per rank",
+                **pj, "bytes_sent_per_gpu": pj["rows_exchanged"] * 8 / n_gpus,
+                "single_gpu_ms_per_step": p1["ms_per_step"], "single_gpu_mrows_per_s": p1["mrows_per_s"],
+                "speedup_vs_1gpu": p1["ms_per_step"] / pj["ms_per_step"],
+                "matches_equal_single_gpu": pj["matches"] == p1["matches"]}
+    except Exception as e:  # keep the line: the other host is still to come
+        if rank == 0:
+            section["torch_distributed_host"] = {"error": repr(e)}
+    if rank == 0 and getattr(args, "pjoin_child", False):  # what is known so far, should the next leg take the process down
+        print(json.dumps(out), flush=True)
+        if os.environ.get("DBENCH_TEST_CHILD_FAULT"):  # test hook: the child of rank 0 dies like a process with a GPU fault
+            import signal
+            os.kill(os.getpid(), signal.SIGSEGV)
+    if os.environ.get("DBENCH_BACKEND", "nccl") == "nccl":  # the C++ engine talks RCCL: needs one GPU per rank
+        try:
+            dog.leg = "C++ engine, all ranks"
+            cx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local)
+            torch.cuda.empty_cache()
+            dog.leg = "C++ engine, one GPU"
+            c1 = bench_pjoin_native(2, 1, pj_log2, dist, rank, world, local, solo=True) if rank == 0 else None
+            barrier()
+            if rank == 0:
+                section.update(cx)
+                section.update({"single_gpu_ms_per_step": c1["ms_per_step"], "single_gpu_mrows_per_s": c1["mrows_per_s"],
+                                "speedup_vs_1gpu": c1["ms_per_step"] / cx["ms_per_step"],
+                                "matches_equal_single_gpu": cx["matches"] == c1["matches"]})
+        except Exception as e:
+            if rank == 0:
+                section["error"] = repr(e)
+    elif rank == 0:
+        section["note"] = "rehearsal backend: ranks share GPUs, the C++ RCCL engine needs one GPU per rank and is skipped"
+    dog.cancel()
+
+
+
+def run_pjoin_children(args, rank):
+    """every rank starts `bench.py --pjoin-child` with its own RANK / LOCAL_RANK / WORLD_SIZE and MASTER_PORT + 1,
+    waits for it (deadline: DBENCH_PJOIN_DEADLINE_S + 60 s) and rank 0 returns the child's section"""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    # under torch.distributed.run the ranks are clients of the launcher's store; the children's rank 0 must host its own
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+    deadline = int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")) + 60
+    cmd = [sys.executable, os.path.abspath(__file__), "--pjoin-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
+    print(f"[bench] rank {rank}: starting the partitioned-join child (port {env['MASTER_PORT']}, deadline {deadline} s)", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        text, _ = proc.communicate(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": f"the partitioned-join child processes did not finish within {deadline} s"}
+    if rank != 0:
+        return None
+    for line in reversed((text or "").strip().splitlines()):
+        try:
+            got = json.loads(line)
+        except ValueError:
+            continue
+        if isinstance(got, dict) and "pjoin" in got:
+            if proc.returncode != 0:
+                got["pjoin"].setdefault("error", f"child exit code {proc.returncode}")
+            return got["pjoin"]
+    return {"error": f"the partitioned-join child of rank 0 ended with exit code {proc.returncode} and no result line"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -476,6 +575,7 @@ def main():
     ap.add_argument("--no-pjoin", action="store_true", help="skip the single-GPU 2^30 x 2^30 join (profiling passes)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the scan selectivity sweep and the reference-range "
                     "sorts (counter passes: keeps every scan / sort dispatch at the BASELINE configuration)")
+    ap.add_argument("--pjoin-child", action="store_true", help=argparse.SUPPRESS)  # see run_pjoin_children
     args = ap.parse_args()
 
     rank, world, local = _dist_env()
@@ -505,6 +605,17 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.pjoin_child:  # the partitioned-join section only; rank 0 prints {"pjoin": section}
+        child_out = {}
+        print(f"[bench] child of rank {rank}: process group up", file=sys.stderr, flush=True)
+        pjoin_section(args, dist, rank, world, local, barrier, child_out)
+        if rank == 0:
+            print(json.dumps(child_out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- headline: scan 2^28 (BASELINE.json's metric configuration)
     barrier()
@@ -593,59 +704,19 @@ def main():
         out["dwarfs"] = dwarfs
 
     if n_gpus > 1:
-        # ---- the one part of the hot path that shards (BASELINE north_star): the hash join, radix-partitioned
-        # across the ranks with an RCCL all-to-all bucket exchange.  STRONG scaling: 2^30 x 2^30 in total whatever N
-        # is.  Two hosts drive the same device kernels and are both reported: the C++ engine of the PartitionedJoinHip
-        # dwarf (`pjoin`, the headline of this section) and the torch.distributed one (`pjoin.torch_distributed_host`).
-        # Each one's single-GPU reference point is measured in this same run, on rank 0's GPU, while the other ranks
-        # wait — so the speed-ups are self-contained in this line.
+        # The partitioned join runs in CHILD processes (one per rank, their own process group one port up): its RCCL
+        # legs have only ever been rehearsed on one GPU, and a native fault there (a GPU memory fault aborts the
+        # process; a hung collective cannot be interrupted) must not cost the contract line above.  Rank 0 reads its
+        # child's JSON; anything else becomes pjoin.error.  DBENCH_PJOIN_INPROCESS=1 runs the section in this process.
         torch.cuda.empty_cache()
-        pj_steps, pj_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
-        pj_log2 = int(os.environ.get("DBENCH_PJOIN_LOG2", "30"))
-        dog = _Watchdog(int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")), rank, out)
-        section = {"metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
-                   "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm}
-        if rank == 0:
-            out["pjoin"] = section
-        try:
-            dog.leg = "torch.distributed host, all ranks"
-            pj = bench_pjoin(pj_steps, pj_warm, pj_log2, dist)
-            torch.cuda.empty_cache()
-            dog.leg = "torch.distributed host, one GPU"
-            solo = dist.new_group(ranks=[0])  # collective call; only rank 0 uses it: its join below is purely local
-            p1 = bench_pjoin(2, 1, pj_log2, None, group=solo) if rank == 0 else None
+        if os.environ.get("DBENCH_PJOIN_INPROCESS"):
+            pjoin_section(args, dist, rank, world, local, barrier, out)
+        else:
             barrier()
-            torch.cuda.empty_cache()
+            section = run_pjoin_children(args, rank)
             if rank == 0:
-                section["torch_distributed_host"] = {
-                    "parallelism": f"hash-partitioned over {n_gpus} ranks, all_to_all bucket exchange (RCCL over xGMI) "
-                                   "overlapped with partition/build, local LDS-partitioned join per rank",
-                    **pj, "bytes_sent_per_gpu": pj["rows_exchanged"] * 8 / n_gpus,
-                    "single_gpu_ms_per_step": p1["ms_per_step"], "single_gpu_mrows_per_s": p1["mrows_per_s"],
-                    "speedup_vs_1gpu": p1["ms_per_step"] / pj["ms_per_step"],
-                    "matches_equal_single_gpu": pj["matches"] == p1["matches"]}
-        except Exception as e:  # keep the line: the other host is still to come
-            if rank == 0:
-                section["torch_distributed_host"] = {"error": repr(e)}
-        if os.environ.get("DBENCH_BACKEND", "nccl") == "nccl":  # the C++ engine talks RCCL: needs one GPU per rank
-            try:
-                dog.leg = "C++ engine, all ranks"
-                cx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local)
-                torch.cuda.empty_cache()
-                dog.leg = "C++ engine, one GPU"
-                c1 = bench_pjoin_native(2, 1, pj_log2, dist, rank, world, local, solo=True) if rank == 0 else None
-                barrier()
-                if rank == 0:
-                    section.update(cx)
-                    section.update({"single_gpu_ms_per_step": c1["ms_per_step"], "single_gpu_mrows_per_s": c1["mrows_per_s"],
-                                    "speedup_vs_1gpu": c1["ms_per_step"] / cx["ms_per_step"],
-                                    "matches_equal_single_gpu": cx["matches"] == c1["matches"]})
-            except Exception as e:
-                if rank == 0:
-                    section["error"] = repr(e)
-        elif rank == 0:
-            section["note"] = "rehearsal backend: ranks share GPUs, the C++ RCCL engine needs one GPU per rank and is skipped"
-        dog.cancel()
+                out["pjoin"] = section
+            barrier()
 
     if rank == 0:
         print(json.dumps(out), flush=True)

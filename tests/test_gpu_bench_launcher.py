@@ -1,0 +1,39 @@
+"""`bench.py --gpus 2` under torch.distributed.run, rehearsed on one GPU (DBENCH_BACKEND=gloo: the ranks share the
+card): ONE JSON line with the contract fields from rank 0, the partitioned-join section measured in child processes —
+and still one line, with the torch.distributed leg's numbers and an error note, when the child of rank 0 dies the way
+a process with a GPU memory fault does."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _launch(port, extra_env):
+    env = {**os.environ, "DBENCH_BACKEND": "gloo", "DBENCH_PJOIN_LOG2": "20", "DBENCH_PJOIN_DEADLINE_S": "60", **extra_env}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("fault", [False, True])
+def test_two_ranks_one_line(fault):
+    r, lines = _launch(29611 if fault else 29601, {"DBENCH_TEST_CHILD_FAULT": "1"} if fault else {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "Mrows/s"
+    pj = d["pjoin"]
+    host = pj["torch_distributed_host"]
+    assert host["matches_equal_single_gpu"] and host["ms_per_step"] > 0
+    if fault:
+        assert "error" in pj and "exit code" in pj["error"], pj
+    else:
+        assert "error" not in pj, pj
