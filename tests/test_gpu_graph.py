@@ -42,6 +42,35 @@ def test_scan_graph_replay(n):
         assert np.array_equal(plan.result().cpu().numpy(), po.copy_if_lt(host.view(np.int32), 50))
 
 
+@pytest.mark.parametrize("n", [5000, (1 << 22) + 5])
+def test_dense_scan_and_exclusive_scan_graph_replay(n):
+    """the two single-launch prefix kernels (ticketed chunks, granules cleared by a fill inside the captured sequence)"""
+    from dwarf_bench_amd import ops
+    src = torch.empty(n, dtype=torch.int32, device="cuda")
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    plan = ops.CopyIfLt(n)
+    _fill(src, po.gen_uniform_u32(n, 1, 1, 10000))
+    lib = __import__("dwarf_bench_amd._capi", fromlist=["lib"]).lib()
+    ws_bytes = lib.dbhip_exclusive_scan_u32_workspace_bytes(n)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+
+    def both():
+        plan.launch(src, 6000, dense=True)
+        rc = lib.dbhip_exclusive_scan_u32(src.data_ptr(), n, 5, out.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+
+    g = _capture(both)
+    for seed in (7, 8):
+        host = po.gen_uniform_u32(n, seed, 1, 10000)
+        _fill(src, host)
+        g.replay()
+        assert np.array_equal(plan.result().cpu().numpy(), po.copy_if_lt(host.view(np.int32), 6000))
+        exp = np.zeros(n, dtype=np.uint32)
+        np.cumsum(host[:-1], dtype=np.uint32, out=exp[1:])
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), exp + np.uint32(5))
+
+
 @pytest.mark.parametrize("n,bits", [(4096, 8), (1 << 20, 8), (300007, 4)])
 def test_sort_graph_replay(n, bits):
     from dwarf_bench_amd import ops
