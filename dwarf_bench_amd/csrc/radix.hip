@@ -126,6 +126,12 @@ __device__ __forceinline__ unsigned lanes_before(LaneMask m) {
 }
 __device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popcount(m.lo) + __builtin_popcount(m.hi); }
 
+// consecutive chunks per histogram workgroup: 4 with 8-bit digits (2^24 keys: rs_chunk_hist 15.9 -> 13.0 us, the sort
+// 217 -> 208 us; 2: 216, 8: 222), 1 with 4-bit digits (16 counts per chunk: nothing to gain, and 1024 chunks in 256
+// workgroups leave CUs idle: 360 -> 377 us with 4)
+template <int BITS>
+constexpr int rs_hist_cpw() { return BITS == 8 ? 4 : 1; }
+
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
                                                                   size_t n, unsigned xor_mask,
@@ -140,56 +146,79 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
   constexpr int kBins = 256, kBytes = 4;
   constexpr int kRadix = 1 << BITS;
   __shared__ unsigned s_hist[kBytes * kBins];  // [0][*] is filled from the chunk counts
-  __shared__ unsigned s_chunk[kBins];
+  constexpr int kCpw = rs_hist_cpw<BITS>();  // consecutive chunks whose pass-0 counts are written side by side
+  __shared__ unsigned s_chunks[kCpw][kBins];
   for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) s_hist[i] = 0;
   const size_t chunk_keys = tiles_per_chunk * kRsTile;
-  for (size_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
-    for (int i = threadIdx.x; i < kBins; i += kRsThreads) s_chunk[i] = 0;
+  const size_t groups = (num_chunks + kCpw - 1) / kCpw;
+  for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
+    for (int i = threadIdx.x; i < kCpw * kBins; i += kRsThreads) (&s_chunks[0][0])[i] = 0;
     __syncthreads();
-    const size_t lo = chunk * chunk_keys;
-    size_t hi = lo + chunk_keys;
-    hi = hi < n ? hi : n;
-    const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
-    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
-    for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
-      const u32x4 v = k4[i];
-      const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
-#pragma unroll
-      for (int p = 0; p < kBytes; ++p) {
-        unsigned *hist = p == 0 ? s_chunk : s_hist + p * kBins;
-        // a byte that is the same in the whole wave (the upper bytes of small keys: the reference's
-        // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
-        const unsigned d0 = (k[0] >> (p * 8)) & (kBins - 1);
-        const unsigned first = __builtin_amdgcn_readfirstlane(d0);
-        const bool same = ((k[0] >> (p * 8)) & (kBins - 1)) == first && ((k[1] >> (p * 8)) & (kBins - 1)) == first &&
-                          ((k[2] >> (p * 8)) & (kBins - 1)) == first && ((k[3] >> (p * 8)) & (kBins - 1)) == first;
-        const unsigned long long active = __ballot(true);
-        if (__ballot(same) == active) {
-          if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
-            atomicAdd(&hist[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * 8)) & (kBins - 1)], 1u);
+#pragma unroll 1
+    for (int cc = 0; cc < kCpw; ++cc) {
+      const size_t chunk = group * kCpw + cc;
+      if (chunk >= num_chunks) break;
+      unsigned *s_chunk = s_chunks[cc];
+      const size_t lo = chunk * chunk_keys;
+      size_t hi = lo + chunk_keys;
+      hi = hi < n ? hi : n;
+      const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
+      const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
+      for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
+        const u32x4 v = k4[i];
+        const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
+  #pragma unroll
+        for (int p = 0; p < kBytes; ++p) {
+          unsigned *hist = p == 0 ? s_chunk : s_hist + p * kBins;
+          // a byte that is the same in the whole wave (the upper bytes of small keys: the reference's
+          // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
+          const unsigned d0 = (k[0] >> (p * 8)) & (kBins - 1);
+          const unsigned first = __builtin_amdgcn_readfirstlane(d0);
+          const bool same = ((k[0] >> (p * 8)) & (kBins - 1)) == first && ((k[1] >> (p * 8)) & (kBins - 1)) == first &&
+                            ((k[2] >> (p * 8)) & (kBins - 1)) == first && ((k[3] >> (p * 8)) & (kBins - 1)) == first;
+          const unsigned long long active = __ballot(true);
+          if (__ballot(same) == active) {
+            if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
+              atomicAdd(&hist[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
+          } else {
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * 8)) & (kBins - 1)], 1u);
+          }
         }
       }
-    }
-    for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
-      const unsigned k = keys[i] ^ xor_mask;
-      atomicAdd(&s_chunk[k & (kBins - 1)], 1u);
-#pragma unroll
-      for (int p = 1; p < kBytes; ++p) atomicAdd(&s_hist[p * kBins + ((k >> (p * 8)) & (kBins - 1))], 1u);
+      for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
+        const unsigned k = keys[i] ^ xor_mask;
+        atomicAdd(&s_chunk[k & (kBins - 1)], 1u);
+  #pragma unroll
+        for (int p = 1; p < kBytes; ++p) atomicAdd(&s_hist[p * kBins + ((k >> (p * 8)) & (kBins - 1))], 1u);
+      }
     }
     __syncthreads();
-    // pass 0's counts of this chunk: the byte bins themselves, or (4-bit digits) their sums over the high nibble
+    // pass 0's counts of these chunks: the byte bins themselves (side by side: one 16-byte store per digit where the
+    // row allows it, see rs_chunk_hist_kernel), or (4-bit digits) their sums over the high nibble
+    const size_t chunk0 = group * kCpw;
     if (BITS == 8) {
-      for (int d = threadIdx.x; d < kRadix; d += kRsThreads) counts0[static_cast<size_t>(d) * num_chunks + chunk] = s_chunk[d];
+      const bool vec = kCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;
+      for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
+        unsigned *row = counts0 + static_cast<size_t>(d) * num_chunks + chunk0;
+        if (vec) {
+          *reinterpret_cast<u32x4 *>(row) = u32x4{s_chunks[0][d], s_chunks[1 % kCpw][d], s_chunks[2 % kCpw][d], s_chunks[3 % kCpw][d]};
+        } else {
+          for (int cc = 0; cc < kCpw && chunk0 + cc < num_chunks; ++cc) row[cc] = s_chunks[cc][d];
+        }
+      }
     } else if (threadIdx.x < kRadix) {
       unsigned c = 0;
 #pragma unroll
-      for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunk[hi4 * 16 + threadIdx.x];
-      counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk] = c;
+      for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunks[0][hi4 * 16 + threadIdx.x];
+      counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk0] = c;
     }
-    for (int d = threadIdx.x; d < kBins; d += kRsThreads) s_hist[d] += s_chunk[d];  // thread d owns s_hist[0][d]
+    for (int d = threadIdx.x; d < kBins; d += kRsThreads) {  // thread d owns s_hist[0][d]
+      unsigned c = 0;
+#pragma unroll
+      for (int cc = 0; cc < kCpw; ++cc) c += s_chunks[cc][d];
+      s_hist[d] += c;
+    }
     __syncthreads();
   }
   __syncthreads();
@@ -246,33 +275,51 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
                                                                    size_t n, int pass, unsigned xor_mask,
                                                                    const RsHeader *hdr, unsigned *counts,
                                                                    size_t tiles_per_chunk, size_t num_chunks) {
+  // A workgroup counts kRsHistCpw CONSECUTIVE chunks and writes, per digit, their counts side by side (one 16-byte
+  // store per digit when the row allows it): with one chunk per workgroup every count was a 4-byte store into a
+  // line of its own — 512 K partial-line writes per pass at 2^24 keys, 16 MiB written back for a 2 MiB matrix.
   constexpr int kRadix = 1 << BITS;
-  __shared__ unsigned s_hist[kRadix];
+  constexpr int kRsHistCpw = rs_hist_cpw<BITS>();
+  __shared__ unsigned s_hist[kRsHistCpw][kRadix];
   const RsPass plan = hdr->pass[pass];
   if (plan.skip) return;
   const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
   const int shift = pass * BITS;
-  const size_t chunk = blockIdx.x;
-  const size_t lo = chunk * tiles_per_chunk * kRsTile;
-  size_t hi = lo + tiles_per_chunk * kRsTile;
-  hi = hi < n ? hi : n;
-  for (int i = threadIdx.x; i < kRadix; i += kRsThreads) s_hist[i] = 0;
+  const size_t chunk0 = static_cast<size_t>(blockIdx.x) * kRsHistCpw;
+  for (int i = threadIdx.x; i < kRsHistCpw * kRadix; i += kRsThreads) (&s_hist[0][0])[i] = 0;
   __syncthreads();
-  // chunk starts are multiples of the tile size: 16-byte loads are aligned
-  const size_t n4 = (hi - lo) / 4;
-  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
-  // (issuing a tile's four 16-byte loads per lane before the first LDS atomic, non-temporal, measured no faster)
-  for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
-    const u32x4 v = k4[i];
-    atomicAdd(&s_hist[((v.x ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-    atomicAdd(&s_hist[((v.y ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-    atomicAdd(&s_hist[((v.z ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-    atomicAdd(&s_hist[((v.w ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+#pragma unroll 1
+  for (int c = 0; c < kRsHistCpw; ++c) {
+    const size_t chunk = chunk0 + c;
+    if (chunk >= num_chunks) break;
+    unsigned *hist = s_hist[c];
+    const size_t lo = chunk * tiles_per_chunk * kRsTile;
+    size_t hi = lo + tiles_per_chunk * kRsTile;
+    hi = hi < n ? hi : n;
+    // chunk starts are multiples of the tile size: 16-byte loads are aligned
+    const size_t n4 = (hi - lo) / 4;
+    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
+    // (issuing a tile's four 16-byte loads per lane before the first LDS atomic, non-temporal, measured no faster)
+    for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
+      const u32x4 v = k4[i];
+      atomicAdd(&hist[((v.x ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+      atomicAdd(&hist[((v.y ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+      atomicAdd(&hist[((v.z ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+      atomicAdd(&hist[((v.w ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+    }
+    for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads)
+      atomicAdd(&hist[((src[i] ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
   }
-  for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads)
-    atomicAdd(&s_hist[((src[i] ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
   __syncthreads();
-  for (int d = threadIdx.x; d < kRadix; d += kRsThreads) counts[static_cast<size_t>(d) * num_chunks + chunk] = s_hist[d];
+  const bool vec = kRsHistCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;  // 16-byte aligned row pieces
+  for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
+    unsigned *row = counts + static_cast<size_t>(d) * num_chunks + chunk0;
+    if (vec) {
+      *reinterpret_cast<u32x4 *>(row) = u32x4{s_hist[0][d], s_hist[1 % kRsHistCpw][d], s_hist[2 % kRsHistCpw][d], s_hist[3 % kRsHistCpw][d]};
+    } else {
+      for (int c = 0; c < kRsHistCpw && chunk0 + c < num_chunks; ++c) row[c] = s_hist[c][d];
+    }
+  }
 }
 
 // ---- per pass, kernel 2: counts[d][*] -> global start of digit d in every chunk ------------------------
@@ -673,7 +720,8 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * 4;
   const unsigned hgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
-  const unsigned hist_grid = static_cast<unsigned>(g.chunks < cap ? g.chunks : cap);
+  const size_t hist_groups = (g.chunks + rs_hist_cpw<BITS>() - 1) / rs_hist_cpw<BITS>();
+  const unsigned hist_grid = static_cast<unsigned>(hist_groups < cap ? hist_groups : cap);
   hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n,
                      xor_mask, totals, counts, g.tiles_per_chunk, g.chunks);
   hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
@@ -681,7 +729,7 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   const bool fused_scan = g.chunks <= kRsFusedScanChunks;
   for (int p = 0; p < kPasses; ++p) {
     if (p > 0)  // pass 0's chunk counts came with the up-front histogram
-      hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
+      hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3((cgrid + rs_hist_cpw<BITS>() - 1) / rs_hist_cpw<BITS>()), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
                          hdr, counts, g.tiles_per_chunk, g.chunks);
     if (!fused_scan)
       hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
