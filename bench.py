@@ -40,9 +40,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300-6970 GB/s is what a bare stream reaches
-RANDOM_GATHER_PEAK_G = 53.0  # G random 4..16-byte gathers/s into a table >= 64 MiB, measured with tools/ubench.hip
-LDS_ATOMIC_PEAK_G = 4000.0   # G random ds_add/s chip-wide, measured with tools/ubench_lds.hip (indices from registers;
-                             # the 830 G/s figure of round 1 came from a loop that was bound by its 4-byte index loads)
+# Two SELF-MEASURED peaks (secondary rooflines of the join probe and the group-by; the contract `roofline` divides by the
+# HBM spec above, never by these).  Source: tools/ubench.hip / tools/ubench_lds.hip, raw output tracked under profiles/
+# (written by tools/profile_round.sh); _peak_source() names the file next to every figure that uses them.
+RANDOM_GATHER_PEAK_G = 53.0  # G random 4..16-byte gathers/s into a table >= 64 MiB ("random 2^26 ops, table 256 MiB" line)
+LDS_ATOMIC_PEAK_G = 4000.0   # G random ds_add/s chip-wide (indices from registers; the 830 G/s figure of round 1 came
+                             # from a loop that was bound by its 4-byte index loads)
 
 
 def _dist_env():
@@ -94,6 +97,16 @@ def _traffic_source():
     except Exception:
         src = None
     return {"file": "profiles/hbm_traffic.json", "measured_in_this_run": False, "provenance": src}
+
+
+def _peak_source():
+    """where RANDOM_GATHER_PEAK_G / LDS_ATOMIC_PEAK_G come from: the newest tracked micro-benchmark output"""
+    files = sorted((ROOT / "profiles").glob("r*_ubench.txt"))
+    if not files:
+        return {"file": None, "tool": "tools/ubench.hip, tools/ubench_lds.hip", "measured_in_this_run": False}
+    head = files[-1].read_text().splitlines()[0:1]
+    return {"file": f"profiles/{files[-1].name}", "tool": "tools/ubench.hip, tools/ubench_lds.hip (tools/profile_round.sh)",
+            "measured_in_this_run": False, "provenance": head[0].lstrip("# ") if head else None}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -189,7 +202,8 @@ def bench_groupby(steps, warmup, log2n=26, groups=1 << 16):
             # one ds_add per row: far from the LDS atomic rate of the chip (so NOT what bounds the kernel: with 2^16
             # groups every row is read by two workgroups, one per 128 KiB key range, at 16 waves per CU)
             "lds_atomic_rate": {"kernel": "gb_aggregate_kernel", "achieved": n / us / 1e3, "peak": LDS_ATOMIC_PEAK_G,
-                                "unit": "G ds_add/s", "frac": n / us / 1e3 / LDS_ATOMIC_PEAK_G},
+                                "unit": "G ds_add/s", "frac": n / us / 1e3 / LDS_ATOMIC_PEAK_G,
+                                "peak_source": _peak_source()},
             "workload": f"GroupBy SUM 2^{log2n} rows / {groups} groups"}
 
 
@@ -213,7 +227,8 @@ def bench_join(steps, warmup, log2n=26):
             # what the probe's access pattern allows: one random table access per probe row; the chip serves ~53 G
             # random 16-B gathers/s from tables >= 64 MiB (tools/ubench.hip), whatever the HBM byte rate
             "roofline_gather": {"bound": "random_gather", "kernel": "jl_probe_kernel", "achieved": n / pu / 1e3,
-                                "peak": RANDOM_GATHER_PEAK_G, "unit": "G gathers/s", "frac": n / pu / 1e3 / RANDOM_GATHER_PEAK_G},
+                                "peak": RANDOM_GATHER_PEAK_G, "unit": "G gathers/s", "frac": n / pu / 1e3 / RANDOM_GATHER_PEAK_G,
+                                "peak_source": _peak_source()},
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 
@@ -336,7 +351,19 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     w = [int(x) for x in words.cpu().tolist()]
     n_ranks = world if multi else 1
-    return {"rows": 2 * total, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
+    exchange = None
+    if multi and last:
+        # what the first real multi-GPU line needs to be readable: bytes per xGMI link and the rate the two send/recv
+        # groups reached (rank 0's last step; a group's span on the exchange stream includes waiting for its peers).
+        # Uniform keys: every rank sends 1/P of its shard of each relation to every rank, 8 bytes per row.
+        link_bytes = total / n_ranks / n_ranks * 8
+        exchange = {"links_per_gpu": n_ranks - 1, "bytes_per_link_per_relation": link_bytes,
+                    "xgmi_link_peak_gbs": 153.0, "min_us_per_relation_at_link_peak": link_bytes / 153e3}
+        for rel in ("r", "s"):
+            us = last.get(f"exchange_{rel}_us") or 0.0
+            exchange[f"exchange_{rel}_us"] = round(us, 1)
+            exchange[f"achieved_gbs_per_link_{rel}"] = (link_bytes / us / 1e3) if us > 0 else None
+    return {"rows": 2 * total, "exchange_links": exchange, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
             "rows_exchanged": w[4], "bytes_sent_per_gpu": w[4] * 8 / n_ranks,
             "max_over_mean_rows_per_rank": float(mx[5]) * n_ranks / max(w[5], 1),
             "checks": {"damaged_pairs": w[0], "misrouted_keys": w[1], "wrong_probe_rows": w[2],
@@ -361,10 +388,24 @@ class _Watchdog:
         self.timer.start()
 
     def _bail(self):
+        # runs on the timer thread while the main thread may still be filling `out`: serialise a snapshot (retry if the
+        # dict changed under the copy), print it on rank 0, and leave with a NON-ZERO code on every rank — a hung process
+        # that has touched the GPU is a failure (run_pjoin_children turns the child's exit code into pjoin.error)
         if self.rank == 0:
-            self.out.setdefault("pjoin", {})["error"] = f"watchdog: leg '{self.leg}' did not finish within {self.seconds} s"
-            print(json.dumps(self.out), flush=True)
-        os._exit(0)
+            import copy
+            line = None
+            for _ in range(5):
+                try:
+                    snap = copy.deepcopy(self.out)
+                    snap.setdefault("pjoin", {})["error"] = (f"watchdog: leg '{self.leg}' did not finish within "
+                                                             f"{self.seconds} s")
+                    line = json.dumps(snap)
+                    break
+                except RuntimeError:  # dictionary changed size during iteration
+                    time.sleep(0.05)
+            print(line or json.dumps({"pjoin": {"error": f"watchdog: leg '{self.leg}' hung"}}), flush=True)
+            sys.stdout.flush()
+        os._exit(3)
 
     def cancel(self):
         self.timer.cancel()
@@ -393,12 +434,13 @@ def scan_selectivity_sweep(src, plan, n):
 
 
 def cpu_baseline_scan(src_dev, filt, budget_s=12.0):
-    """The oracle's chunked scan (scan.cl restated, T chunks on T threads) on a bounded sample of the same column."""
+    """The oracle's chunked scan (scan.cl restated, T chunks on T threads) on the WHOLE column of the timed
+    configuration (scan/scan.cpp:107-128 times the full input), repeated for about budget_s seconds."""
     import numpy as np
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
-    m = min(src_dev.numel(), 1 << 26)  # 256 MiB of the same column
-    host = src_dev[:m].cpu().numpy()
+    m = src_dev.numel()  # the full 2^28 rows (1 GiB on the host)
+    host = src_dev.cpu().numpy()
     out = np.empty(m, dtype=np.int32)
     po.chunked_scan(host, filt, cores, out)  # warm (page faults)
     reps, t_total = 0, 0.0
@@ -413,7 +455,7 @@ def cpu_baseline_scan(src_dev, filt, budget_s=12.0):
     po.chunked_scan(host[:m1], filt, 1, out)
     t1 = time.perf_counter() - t0
     return {"value": m * reps / t_total / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
-            "sample": f"first 2^{m.bit_length() - 1} rows of the same column, {reps} passes, {cores} threads "
+            "sample": f"the whole column (2^{m.bit_length() - 1} rows), {reps} passes, {cores} threads "
                       f"(oracle/dbo.c dbo_chunked_scan_i32 = scan/scan.cl:3-42 with T chunks)",
             "single_thread_mrows_per_s": m1 / t1 / 1e6}
 
@@ -442,28 +484,30 @@ def cpu_baselines_dwarfs(which):
                        "sample": f"the full 2^24 full-range keys, {reps} sorts (oracle dbo_radix_sort_u32_mt: parallel LSD "
                                  f"radix, the role TBBSort/std::sort play in sort/tbbsort.cpp:22, sort/radix.cpp:8-12)"}
     if "groupby" in which:
-        n, groups = 1 << 24, 1 << 16
+        n, groups = 1 << 26, 1 << 16  # the full configuration (groupby/groupby.cpp:57-94 times the full input)
         keys = po.gen_uniform_u32(n, 42, 0, groups - 1)
         vals = po.gen_uniform_u32(n, 43, 1, 10000)
         reps, t_total = 0, 0.0
-        while t_total < 4.0 and reps < 20:
+        while t_total < 6.0 and reps < 20:
             t0 = time.perf_counter()
             po.groupby_hash(keys, vals, groups, threads=cores)
             t_total += time.perf_counter() - t0
             reps += 1
         out["groupby"] = {"value": n / (t_total / reps) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
-                          "sample": f"first 2^24 rows of the same columns, 2^16 groups, {reps} passes (oracle "
-                                    f"dbo_groupby_hash_u32 = CAS + fetch_add table of groupby/groupby.cpp:58-93, "
-                                    f"hashtable.hpp:136-153)"}
+                          "sample": f"the whole 2^26-row columns, 2^16 groups, {reps} passes (oracle dbo_groupby_hash_u32 = the "
+                                    f"reference's algorithm as it stands: ONE global CAS + fetch_add table of n slots, "
+                                    f"groupby/groupby.cpp:58-93, hashtable.hpp:136-153 — every row of a group contends for "
+                                    f"the same slot, which is what this figure measures on {cores} cores)"}
     if "join" in which:
-        n = 1 << 22
-        build = po.gen_uniform_u32(n, 42, 0, (1 << 26) - 1)  # the first 2^22 rows of the 2^26 columns
-        probe = po.gen_uniform_u32(n, 43, 0, (1 << 26) - 1)
+        n = 1 << 26  # the full configuration (join/join_omnisci.cpp:78-88 times the full input); ~3 GiB of host tables
+        build = po.gen_uniform_u32(n, 42, 0, n - 1)
+        probe = po.gen_uniform_u32(n, 43, 0, n - 1)
         bs, ps, _ = po.join_omnisci_timings(build, probe, cores)
         out["join"] = {"value": 2 * n / (bs + ps) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
                        "build_s": bs, "probe_s": ps,
-                       "sample": "first 2^22 rows of both 2^26 key columns, one build + probe (oracle dbo_join_build/"
-                                 "dbo_join_probe = omnisci_hashtable.hpp:80-192 with std::atomic)"}
+                       "sample": "the whole 2^26-row key columns of the timed configuration, one build + probe (oracle "
+                                 "dbo_join_build/dbo_join_probe = omnisci_hashtable.hpp:80-192 with std::atomic; ht_size = "
+                                 "2*distinct(build) computed outside the timed part as join_omnisci.cpp:69 does)"}
     return out
 
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dbhip_radix_sort_u32": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp]),
     "dbhip_radix_sort_i32": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp]),
     "dbhip_radix_sort_rank_mode": (_int, []),
+    "dbhip_radix_sort_prepare": (_int, [_vp]),
     "dbhip_groupby_sum_u32_workspace_bytes": (_sz, [_sz, _u32]),
     "dbhip_groupby_sum_u32": (_int, [_vp, _vp, _sz, _u32, _vp, _vp, _sz, _vp]),
     "dbhip_groupby_partial_u32": (_int, [_vp, _vp, _sz, _u32, _u32, _vp, _sz, _vp]),

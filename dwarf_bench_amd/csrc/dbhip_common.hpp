@@ -26,6 +26,7 @@ struct DeviceInfo {
   int cus = 0;
   int wave = 0;
   bool ok = false;
+  bool gfx950 = false;  // the architecture this library is written and checked for (allow-list of the sort's LDS-atomic ranking)
 };
 const DeviceInfo &current_device_info();  // cached per device (dbhip_util.hip)
 

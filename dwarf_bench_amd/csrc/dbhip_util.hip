@@ -23,6 +23,7 @@ const DeviceInfo &current_device_info() {
       d.cus = p.multiProcessorCount;
       d.wave = p.warpSize;
       d.ok = d.cus > 0 && d.wave == kWave;
+      d.gfx950 = std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
     }
   }
   return d;

@@ -3,29 +3,33 @@
 // Replaces oneDPL's std::sort(device_policy) behind Radix/RadixCuda (dpl_wrapper.hpp:35-39 <-
 // sort/radix.cpp:34); result identical to std::sort (sort/radix.cpp:8-12).
 //
-// Structure (digit width BITS = 8 tuned, 4 = the configuration named in BASELINE.json):
-//   1. rs_histogram      one read of the keys: global digit totals for EVERY pass (LDS histograms per
-//                        workgroup, one coalesced atomic flush per workgroup).
-//   2. rs_plan           one workgroup: per pass the exclusive digit bases, and which passes are skipped
-//                        because their digit is constant over the whole input (e.g. keys in [1,10000]
-//                        skip the two upper bytes); fixes the ping-pong parity of every pass.
-//   3. per executed pass, three kernels over CHUNKS of consecutive 8192-key tiles, with no communication
-//      between workgroups inside a kernel:
-//        rs_chunk_hist     digit counts of every chunk (LDS histogram) -> counts[digit][chunk]
-//        rs_chunk_scan     one workgroup per digit: exclusive scan of its row + the digit base
-//        rs_chunk_scatter  one workgroup per chunk, tile by tile: each wave ranks its 1024 keys stably
-//                          with wave64 match masks (BITS ballots per key — CDNA has no match
-//                          instruction —, v_mbcnt for the lane rank, wave-private LDS digit counters),
-//                          the tile is re-ordered by digit through LDS and written out in digit order,
-//                          so consecutive lanes hit consecutive addresses; the chunk's running
-//                          per-digit offsets live in registers of the digit-owner threads.
-//      (A single-pass Onesweep with decoupled look-back was measured first: 106 us per 8-bit pass at
-//      2^24 keys, dominated by look-back waits between tiles in flight; same finding as in scan.hip.)
-//   4. rs_finalize       copies tmp -> keys when an odd number of passes ran.
+// Digit width BITS = 8 (tuned) or 4 (the configuration named in BASELINE.json).  Work is cut into CHUNKS of consecutive
+// 8192-key tiles; a pass needs, for every chunk, the number of keys per digit (-> where the chunk's keys of that digit
+// go), then scatters chunk by chunk with no communication between workgroups:
+//   rs_chunk_scatter  one workgroup per chunk, tile by tile: each wave ranks its 1024 keys stably (one returning LDS
+//                     atomic per key, or BITS ballots per key — CDNA has no match instruction), the tile is re-ordered
+//                     by digit through LDS and written out in digit order, so consecutive lanes hit consecutive
+//                     addresses; the chunk's running per-digit offsets live in registers of the digit-owner threads.
+// What differs between the digit widths is where the per-chunk counts come from:
+//   8-bit   rs_upfront (one read of the keys: digit 0's counts per chunk + which key bits vary at all) and, for every
+//           later pass, rs_chunk_hist (a second read of the pass's input) -> rs_chunk_scan (one workgroup per digit:
+//           exclusive scan of its row, row total) -> scatter (adds the digit base: exclusive scan of the 256 totals).
+//   4-bit   READ ONCE PER PASS (round 3): the scatter of pass k counts, while it writes a key to its final position,
+//           the key's NEXT digit d' into an LDS table indexed by (destination chunk, d, d') — a chunk's keys of digit d
+//           are one contiguous run of the output, which lies in at most two of the next pass's (position-defined)
+//           chunks, so the table has 2 x 16 x 16 counters — and adds the table to the next pass's count matrix with
+//           512 coalesced global atomics per workgroup.  Per pass: rs_scan4 (ONE workgroup: offsets of every chunk and
+//           digit, clears the matrix the scatter is about to fill) -> scatter.  With 8-bit digits the same table would
+//           have 2 x 256 x 256 counters per chunk and about one key per counter: no aggregation, one global atomic per
+//           key — the 8-bit sort keeps its second read.
+// Passes whose digit bits do not vary over the input (OR of the keys & OR of their complements, taken by rs_upfront)
+// are skipped by every kernel on that device-side word: no host round trip, no plan kernel; each kernel derives the
+// ping-pong parity of its pass from the same word.  rs_finalize copies tmp -> keys after an odd number of passes.
+// (A single-pass Onesweep with decoupled look-back was measured in round 1: 106 us per 8-bit pass at 2^24 keys,
+// dominated by look-back waits between tiles in flight; same finding as in scan.hip.)
 //
-// Bytes: 4N (histogram) + P * 12N (chunk histogram read + scatter read/write), P <= 32/BITS; at 2^24
-// keys both ping-pong buffers (128 MiB) live in the 256 MiB Infinity Cache.  Everything between passes
-// stays device-side (skipped passes return at once on a device-side flag, no host round trip).
+// Bytes: 8-bit 4N + 8N + 3 * 12N; 4-bit 4N + P * 8N, P <= 8; at 2^24 keys both ping-pong buffers (128 MiB) live in
+// the 256 MiB Infinity Cache.
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -54,35 +58,50 @@ constexpr int kRsWaves = kRsThreads / kWave;
 constexpr int kRsKpt = DBHIP_RS_KPT;             // keys per lane per tile
 constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
-constexpr int kRsMaxPasses = 8;
 constexpr int kRsMaxRadix = 256;
 #ifndef DBHIP_RS_CHUNKS
 #define DBHIP_RS_CHUNKS 2048
 #endif
 constexpr size_t kRsTargetChunks = DBHIP_RS_CHUNKS;  // chunks per pass (>= 8 per CU for balance)
-constexpr size_t kRsFusedScanChunks = 32;        // up to this many chunks the scatter sums its own prefix (2^16 keys: 89 -> 80 us; at 128 chunks it costs 17 us)
+constexpr size_t kRsFusedScanChunks = 32;        // 8-bit: up to this many chunks the scatter sums its own prefix (2^16 keys: 89 -> 80 us; at 128 chunks it costs 17 us)
+constexpr size_t kRs4MaxChunks = kRsTargetChunks / 2;  // 4-bit: at most this many chunks, one thread of rs_scan4 each
+static_assert(kRs4MaxChunks <= 1024, "rs_scan4 is one workgroup with one thread per chunk");
 
-struct RsPass {
-  unsigned skip;        // digit constant over the input: the pass's kernels return immediately
-  unsigned src_is_tmp;  // which buffer holds the keys when this pass starts
-};
 struct RsHeader {
   unsigned status;
-  unsigned final_in_tmp;
-  unsigned pad0[6];
-  RsPass pass[kRsMaxPasses];
-  unsigned pad1[64 - 8 - 2 * kRsMaxPasses];
+  // which key bits take both values somewhere in the input = or_bits & nor_bits (OR of the keys, OR of their
+  // complements; both start at 0 with the cleared header).  A pass is skipped iff none of its digit's bits varies.
+  unsigned or_bits, nor_bits;
+  unsigned pad[61];
 };
 static_assert(sizeof(RsHeader) == kWsHeader, "workspace header size");
 
-// workspace: header | totals[8][256] | bases[8][256] | counts[radix][chunks]
-// (Measured and dropped for 4-bit digits: per-pass sums of the chunk counts over groups of 64 chunks, added by the
-// histogram workgroups with 16 global atomics each, so that the scatter could find its offsets without a scan kernel —
-// the 2048 workgroups hammer the same 32 cache lines of sums: rs_chunk_hist 12.5 -> 28 us, scatter 31 -> 35 us,
-// 2^24 keys 458 -> 518 us.)
+// what every kernel derives from the header word for ITS pass
+template <int BITS>
+__device__ __forceinline__ bool rs_varies(unsigned varying, int pass) {
+  return ((varying >> (pass * BITS)) & ((1u << BITS) - 1u)) != 0u;
+}
+template <int BITS>
+__device__ __forceinline__ unsigned rs_parity(unsigned varying, int pass) {  // passes executed before `pass`, mod 2
+  unsigned par = 0;
+  for (int q = 0; q < pass; ++q) par ^= rs_varies<BITS>(varying, q) ? 1u : 0u;
+  return par;
+}
+template <int BITS>
+__device__ __forceinline__ int rs_next_pass(unsigned varying, int pass) {  // next executed pass after `pass`, or -1
+  for (int q = pass + 1; q < 32 / BITS; ++q)
+    if (rs_varies<BITS>(varying, q)) return q;
+  return -1;
+}
+
+// workspace, 8-bit: header | totals[4][256] | counts[256][chunks] (turned into offsets in place by rs_chunk_scan)
+//            4-bit: header | cnt[2][chunks][16] (the matrix of the current pass and the one the scatter fills) | off[chunks][16]
+// (Measured and dropped for 4-bit digits in round 1: per-pass sums of the chunk counts over groups of 64 chunks, added by
+// the histogram workgroups with 16 global atomics each, so that the scatter could find its offsets without a scan
+// kernel — the 2048 workgroups hammer the same 32 cache lines of sums: rs_chunk_hist 12.5 -> 28 us.)
 constexpr size_t kRsTotalsOff = kWsHeader;
-constexpr size_t kRsBasesOff = kRsTotalsOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
-constexpr size_t kRsCountsOff = kRsBasesOff + sizeof(unsigned) * kRsMaxPasses * kRsMaxRadix;
+constexpr size_t kRsCountsOff = kRsTotalsOff + sizeof(unsigned) * 4 * kRsMaxRadix;  // 8-bit
+constexpr size_t kRs4CntOff = kWsHeader;                                            // 4-bit
 
 struct RsGeometry {
   size_t tiles, tiles_per_chunk, chunks;
@@ -90,7 +109,7 @@ struct RsGeometry {
 inline RsGeometry rs_geometry(size_t n, int bits) {
   RsGeometry g;
   // 4-bit digits: half as many, twice as long chunks (2^24 keys: 378 -> 363 us; 8-bit digits: no difference)
-  const size_t target = bits == 4 ? kRsTargetChunks / 2 : kRsTargetChunks;
+  const size_t target = bits == 4 ? kRs4MaxChunks : kRsTargetChunks;
   g.tiles = (n + kRsTile - 1) / kRsTile;
   g.tiles_per_chunk = (g.tiles + target - 1) / target;
   if (g.tiles_per_chunk == 0) g.tiles_per_chunk = 1;
@@ -127,205 +146,149 @@ __device__ __forceinline__ unsigned lanes_before(LaneMask m) {
 __device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popcount(m.lo) + __builtin_popcount(m.hi); }
 
 // consecutive chunks per histogram workgroup: 4 with 8-bit digits (2^24 keys: rs_chunk_hist 15.9 -> 13.0 us, the sort
-// 217 -> 208 us; 2: 216, 8: 222), 1 with 4-bit digits (16 counts per chunk: nothing to gain, and 1024 chunks in 256
-// workgroups leave CUs idle: 360 -> 377 us with 4)
+// 217 -> 208 us; 2: 216, 8: 222), 1 with 4-bit digits (16 counts per chunk are one 64-byte row: nothing to gain)
 template <int BITS>
 constexpr int rs_hist_cpw() { return BITS == 8 ? 4 : 1; }
 
+// Byte histogram of one chunk into s_bins[256] (LDS, cleared by the caller): one ds_add per key on the byte that holds
+// the pass's digit.  A byte that is the same in the whole wave (upper bytes of small keys: the reference's [1,10000]
+// data) would serialise 64 same-address ds_add: one lane adds the lot instead.
+__device__ __forceinline__ void rs_count_chunk_bytes(const unsigned *__restrict__ src, size_t lo, size_t hi, int byte_shift,
+                                                     unsigned xor_mask, unsigned *s_bins, unsigned &my_or, unsigned &my_nor) {
+  const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
+  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
+  // (issuing a tile's four 16-byte loads per lane before the first LDS atomic, non-temporal, measured no faster)
+  for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
+    const u32x4 v = k4[i];
+    my_or |= v.x | v.y | v.z | v.w;
+    my_nor |= ~(v.x & v.y & v.z & v.w);
+    const unsigned b0 = ((v.x ^ xor_mask) >> byte_shift) & 255u, b1 = ((v.y ^ xor_mask) >> byte_shift) & 255u,
+                   b2 = ((v.z ^ xor_mask) >> byte_shift) & 255u, b3 = ((v.w ^ xor_mask) >> byte_shift) & 255u;
+    const unsigned first = __builtin_amdgcn_readfirstlane(b0);
+    const bool same = b0 == first && b1 == first && b2 == first && b3 == first;
+    const unsigned long long active = __ballot(true);
+    if (__ballot(same) == active) {
+      if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
+        atomicAdd(&s_bins[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
+    } else {
+      atomicAdd(&s_bins[b0], 1u);
+      atomicAdd(&s_bins[b1], 1u);
+      atomicAdd(&s_bins[b2], 1u);
+      atomicAdd(&s_bins[b3], 1u);
+    }
+  }
+  for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
+    const unsigned k = src[i];
+    my_or |= k;
+    my_nor |= ~k;
+    atomicAdd(&s_bins[((k ^ xor_mask) >> byte_shift) & 255u], 1u);
+  }
+}
+
+// Store the digit counts of the kCpw chunks a histogram workgroup has counted (s_bins[cc][256] byte bins).
+//   8-bit: counts[d][chunk], the kCpw counts of a digit side by side: one 16-byte store per digit when the row allows
+//          it (with one chunk per workgroup every count was a 4-byte store into a line of its own: 512 K partial-line
+//          writes per pass at 2^24 keys, 16 MiB written back for a 2 MiB matrix);
+//   4-bit: cnt[chunk][16]: the nibble's counts are sums of the byte bins over the other nibble.
 template <int BITS>
-__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
-                                                                  size_t n, unsigned xor_mask,
-                                                                  unsigned *__restrict__ totals,
-                                                                  unsigned *__restrict__ counts0,
-                                                                  size_t tiles_per_chunk, size_t num_chunks) {
-  // One read of the keys: digit totals of EVERY pass and, because the workgroups walk the input chunk by chunk,
-  // the per-chunk digit counts of pass 0 as well (counts0[digit][chunk]) — the first pass then needs no
-  // rs_chunk_hist of its own.  The LDS histograms are always over BYTES (four ds_add per key): with 4-bit digits the
-  // two nibble histograms of a byte are its row and column sums, taken once per chunk / once at the end — eight
-  // ds_add per key made this kernel 70 us at 2^24 keys against 32 us for the byte version.
-  constexpr int kBins = 256, kBytes = 4;
-  constexpr int kRadix = 1 << BITS;
-  __shared__ unsigned s_hist[kBytes * kBins];  // [0][*] is filled from the chunk counts
-  constexpr int kCpw = rs_hist_cpw<BITS>();  // consecutive chunks whose pass-0 counts are written side by side
-  __shared__ unsigned s_chunks[kCpw][kBins];
-  for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) s_hist[i] = 0;
+__device__ __forceinline__ void rs_store_chunk_counts(unsigned (*s_bins)[256], unsigned *counts, size_t chunk0,
+                                                      size_t num_chunks, int high_nibble) {
+  constexpr int kCpw = rs_hist_cpw<BITS>();
+  if (BITS == 8) {
+    const bool vec = kCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;
+    for (int d = threadIdx.x; d < 256; d += kRsThreads) {
+      unsigned *row = counts + static_cast<size_t>(d) * num_chunks + chunk0;
+      if (vec) {
+        *reinterpret_cast<u32x4 *>(row) = u32x4{s_bins[0][d], s_bins[1 % kCpw][d], s_bins[2 % kCpw][d], s_bins[3 % kCpw][d]};
+      } else {
+        for (int cc = 0; cc < kCpw && chunk0 + cc < num_chunks; ++cc) row[cc] = s_bins[cc][d];
+      }
+    }
+  } else if (threadIdx.x < 16) {
+    unsigned c = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) c += s_bins[0][high_nibble ? threadIdx.x * 16 + o : o * 16 + threadIdx.x];
+    counts[chunk0 * 16 + threadIdx.x] = c;
+  }
+}
+
+// ---- one read of the keys up front: digit 0's counts of every chunk, and which key bits vary at all ---------------
+// (Rounds 1-2 took the digit totals of ALL passes here — four ds_add per key on byte bins, 28.7 us at 2^24 keys against
+// ~13 us for one; the totals now come out of the per-pass scan and every skip decision out of the two OR words.)
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void rs_upfront_kernel(const unsigned *__restrict__ keys, size_t n, unsigned xor_mask,
+                                                                RsHeader *hdr, unsigned *__restrict__ counts0,
+                                                                size_t tiles_per_chunk, size_t num_chunks) {
+  constexpr int kCpw = rs_hist_cpw<BITS>();
+  __shared__ unsigned s_bins[kCpw][256];
+  __shared__ unsigned s_or, s_nor;
+  if (threadIdx.x == 0) s_or = s_nor = 0;
+  unsigned my_or = 0, my_nor = 0;
   const size_t chunk_keys = tiles_per_chunk * kRsTile;
   const size_t groups = (num_chunks + kCpw - 1) / kCpw;
   for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
-    for (int i = threadIdx.x; i < kCpw * kBins; i += kRsThreads) (&s_chunks[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kCpw * 256; i += kRsThreads) (&s_bins[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int cc = 0; cc < kCpw; ++cc) {
       const size_t chunk = group * kCpw + cc;
       if (chunk >= num_chunks) break;
-      unsigned *s_chunk = s_chunks[cc];
       const size_t lo = chunk * chunk_keys;
-      size_t hi = lo + chunk_keys;
-      hi = hi < n ? hi : n;
-      const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
-      const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
-      for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
-        const u32x4 v = k4[i];
-        const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
-  #pragma unroll
-        for (int p = 0; p < kBytes; ++p) {
-          unsigned *hist = p == 0 ? s_chunk : s_hist + p * kBins;
-          // a byte that is the same in the whole wave (the upper bytes of small keys: the reference's
-          // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
-          const unsigned d0 = (k[0] >> (p * 8)) & (kBins - 1);
-          const unsigned first = __builtin_amdgcn_readfirstlane(d0);
-          const bool same = ((k[0] >> (p * 8)) & (kBins - 1)) == first && ((k[1] >> (p * 8)) & (kBins - 1)) == first &&
-                            ((k[2] >> (p * 8)) & (kBins - 1)) == first && ((k[3] >> (p * 8)) & (kBins - 1)) == first;
-          const unsigned long long active = __ballot(true);
-          if (__ballot(same) == active) {
-            if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
-              atomicAdd(&hist[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
-          } else {
-  #pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(&hist[(k[c] >> (p * 8)) & (kBins - 1)], 1u);
-          }
-        }
-      }
-      for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
-        const unsigned k = keys[i] ^ xor_mask;
-        atomicAdd(&s_chunk[k & (kBins - 1)], 1u);
-  #pragma unroll
-        for (int p = 1; p < kBytes; ++p) atomicAdd(&s_hist[p * kBins + ((k >> (p * 8)) & (kBins - 1))], 1u);
-      }
+      const size_t hi = lo + chunk_keys < n ? lo + chunk_keys : n;
+      rs_count_chunk_bytes(keys, lo, hi, 0, xor_mask, s_bins[cc], my_or, my_nor);
     }
     __syncthreads();
-    // pass 0's counts of these chunks: the byte bins themselves (side by side: one 16-byte store per digit where the
-    // row allows it, see rs_chunk_hist_kernel), or (4-bit digits) their sums over the high nibble
-    const size_t chunk0 = group * kCpw;
-    if (BITS == 8) {
-      const bool vec = kCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;
-      for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
-        unsigned *row = counts0 + static_cast<size_t>(d) * num_chunks + chunk0;
-        if (vec) {
-          *reinterpret_cast<u32x4 *>(row) = u32x4{s_chunks[0][d], s_chunks[1 % kCpw][d], s_chunks[2 % kCpw][d], s_chunks[3 % kCpw][d]};
-        } else {
-          for (int cc = 0; cc < kCpw && chunk0 + cc < num_chunks; ++cc) row[cc] = s_chunks[cc][d];
-        }
-      }
-    } else if (threadIdx.x < kRadix) {
-      unsigned c = 0;
-#pragma unroll
-      for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunks[0][hi4 * 16 + threadIdx.x];
-      counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk0] = c;
-    }
-    for (int d = threadIdx.x; d < kBins; d += kRsThreads) {  // thread d owns s_hist[0][d]
-      unsigned c = 0;
-#pragma unroll
-      for (int cc = 0; cc < kCpw; ++cc) c += s_chunks[cc][d];
-      s_hist[d] += c;
-    }
+    rs_store_chunk_counts<BITS>(s_bins, counts0, group * kCpw, num_chunks, 0);
     __syncthreads();
   }
+  if (my_or) atomicOr(&s_or, my_or);
+  if (my_nor) atomicOr(&s_nor, my_nor);
   __syncthreads();
-  if (BITS == 8) {
-    for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) {
-      const unsigned c = s_hist[i];
-      if (c) atomicAdd(&totals[(i / kBins) * kRsMaxRadix + (i % kBins)], c);
-    }
-  } else if (threadIdx.x < kBytes * 2 * kRadix) {  // 8 passes x 16 digits: pass 2q = low nibble of byte q, 2q+1 = high
-    const unsigned pass = threadIdx.x / kRadix, d = threadIdx.x % kRadix, byte = pass / 2;
-    unsigned c = 0;
-#pragma unroll
-    for (int o = 0; o < 16; ++o) c += s_hist[byte * kBins + ((pass & 1u) ? d * 16 + o : o * 16 + d)];
-    if (c) atomicAdd(&totals[pass * kRsMaxRadix + d], c);
+  if (threadIdx.x == 0) {
+    if (s_or) atomicOr(&hdr->or_bits, s_or);
+    if (s_nor) atomicOr(&hdr->nor_bits, s_nor);
   }
 }
 
-template <int BITS>
-__global__ __launch_bounds__(kRsThreads) void rs_plan_kernel(size_t n, RsHeader *hdr,
-                                                             const unsigned *__restrict__ totals,
-                                                             unsigned *__restrict__ bases) {
-  constexpr int kRadix = 1 << BITS;
-  constexpr int kPasses = 32 / BITS;
-  __shared__ unsigned s_wsum[kRsWaves];
-  __shared__ unsigned s_skip[kPasses];
-  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  if (tid < kPasses) s_skip[tid] = 0;
-  __syncthreads();
-  for (int p = 0; p < kPasses; ++p) {
-    const unsigned t = tid < kRadix ? totals[p * kRsMaxRadix + tid] : 0u;
-    if (t == n) s_skip[p] = 1;
-    const unsigned incl = wave_inclusive_scan(t);
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned off = 0;
-    for (unsigned w = 0; w < wave; ++w) off += s_wsum[w];
-    if (tid < kRadix) bases[p * kRsMaxRadix + tid] = off + incl - t;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    unsigned cur = 0;
-    for (int p = 0; p < kPasses; ++p) {
-      hdr->pass[p].skip = s_skip[p];
-      hdr->pass[p].src_is_tmp = cur;
-      if (!s_skip[p]) cur ^= 1u;
-    }
-    hdr->final_in_tmp = cur;
-  }
-}
-
-// ---- per pass, kernel 1: digit counts of every chunk -------------------------------------------------
-template <int BITS>
-__global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigned *keys, const unsigned *tmp,
-                                                                   size_t n, int pass, unsigned xor_mask,
-                                                                   const RsHeader *hdr, unsigned *counts,
+// ---- digit counts of every chunk by a second read of the pass's input -------------------------------------------
+// 8-bit: every pass after the first.  4-bit: launched once after rs_upfront and does something only when digit 0 turned
+// out constant (FIRST = true: it counts the first digit that varies — the rest of the 4-bit pipeline gets its counts
+// from the previous pass's scatter).
+template <int BITS, bool FIRST>
+__global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigned *keys, const unsigned *tmp, size_t n, int pass,
+                                                                   unsigned xor_mask, const RsHeader *hdr, unsigned *counts,
                                                                    size_t tiles_per_chunk, size_t num_chunks) {
-  // A workgroup counts kRsHistCpw CONSECUTIVE chunks and writes, per digit, their counts side by side (one 16-byte
-  // store per digit when the row allows it): with one chunk per workgroup every count was a 4-byte store into a
-  // line of its own — 512 K partial-line writes per pass at 2^24 keys, 16 MiB written back for a 2 MiB matrix.
-  constexpr int kRadix = 1 << BITS;
-  constexpr int kRsHistCpw = rs_hist_cpw<BITS>();
-  __shared__ unsigned s_hist[kRsHistCpw][kRadix];
-  const RsPass plan = hdr->pass[pass];
-  if (plan.skip) return;
-  const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
-  const int shift = pass * BITS;
-  const size_t chunk0 = static_cast<size_t>(blockIdx.x) * kRsHistCpw;
-  for (int i = threadIdx.x; i < kRsHistCpw * kRadix; i += kRsThreads) (&s_hist[0][0])[i] = 0;
+  constexpr int kCpw = rs_hist_cpw<BITS>();
+  __shared__ unsigned s_bins[kCpw][256];
+  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+  if (FIRST) {
+    if (rs_varies<BITS>(varying, 0)) return;  // the common case: rs_upfront counted the right digit
+    pass = rs_next_pass<BITS>(varying, 0);
+    if (pass < 0) return;  // all keys equal: nothing to sort
+  } else if (!rs_varies<BITS>(varying, pass)) {
+    return;
+  }
+  const unsigned *__restrict__ src = rs_parity<BITS>(varying, pass) ? tmp : keys;
+  const int byte_shift = (pass * BITS) & ~7;
+  const size_t chunk0 = static_cast<size_t>(blockIdx.x) * kCpw;
+  for (int i = threadIdx.x; i < kCpw * 256; i += kRsThreads) (&s_bins[0][0])[i] = 0;
   __syncthreads();
+  unsigned unused_or = 0, unused_nor = 0;
 #pragma unroll 1
-  for (int c = 0; c < kRsHistCpw; ++c) {
+  for (int c = 0; c < kCpw; ++c) {
     const size_t chunk = chunk0 + c;
     if (chunk >= num_chunks) break;
-    unsigned *hist = s_hist[c];
     const size_t lo = chunk * tiles_per_chunk * kRsTile;
     size_t hi = lo + tiles_per_chunk * kRsTile;
     hi = hi < n ? hi : n;
-    // chunk starts are multiples of the tile size: 16-byte loads are aligned
-    const size_t n4 = (hi - lo) / 4;
-    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
-    // (issuing a tile's four 16-byte loads per lane before the first LDS atomic, non-temporal, measured no faster)
-    for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
-      const u32x4 v = k4[i];
-      atomicAdd(&hist[((v.x ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-      atomicAdd(&hist[((v.y ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-      atomicAdd(&hist[((v.z ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-      atomicAdd(&hist[((v.w ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
-    }
-    for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads)
-      atomicAdd(&hist[((src[i] ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
+    rs_count_chunk_bytes(src, lo, hi, byte_shift, xor_mask, s_bins[c], unused_or, unused_nor);
   }
   __syncthreads();
-  const bool vec = kRsHistCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;  // 16-byte aligned row pieces
-  for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
-    unsigned *row = counts + static_cast<size_t>(d) * num_chunks + chunk0;
-    if (vec) {
-      *reinterpret_cast<u32x4 *>(row) = u32x4{s_hist[0][d], s_hist[1 % kRsHistCpw][d], s_hist[2 % kRsHistCpw][d], s_hist[3 % kRsHistCpw][d]};
-    } else {
-      for (int c = 0; c < kRsHistCpw && chunk0 + c < num_chunks; ++c) row[c] = s_hist[c][d];
-    }
-  }
+  rs_store_chunk_counts<BITS>(s_bins, counts, chunk0, num_chunks, BITS == 4 ? (pass & 1) : 0);
 }
 
-// ---- per pass, kernel 2: counts[d][*] -> global start of digit d in every chunk ------------------------
-template <int BITS>
-__global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, const RsHeader *hdr,
-                                                                   const unsigned *__restrict__ bases,
+// ---- 8-bit, per pass: counts[d][*] -> start of digit d in every chunk relative to the digit's base; row total ----------
+__global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, const RsHeader *hdr, unsigned *__restrict__ totals,
                                                                    unsigned *counts, size_t num_chunks) {
   // one workgroup per digit, ONE sweep: every thread takes `per` consecutive chunk counts (<= 8: at most 4096 chunks),
   // wave scan of the thread sums, wave sums through LDS (a loop of 512-chunk rounds with three barriers each took 5 us
@@ -333,7 +296,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   constexpr unsigned kMaxPer = 8;
   static_assert(kRsTargetChunks <= static_cast<size_t>(kMaxPer) * kRsThreads, "chunks per scan workgroup");
   __shared__ unsigned s_wsum[kRsWaves];
-  if (hdr->pass[pass].skip) return;
+  if (!rs_varies<8>(hdr->or_bits & hdr->nor_bits, pass)) return;
   const unsigned d = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned *row = counts + static_cast<size_t>(d) * num_chunks;
   const unsigned per = static_cast<unsigned>((num_chunks + kRsThreads - 1) / kRsThreads);
@@ -347,8 +310,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   const unsigned incl = wave_inclusive_scan(mine);
   if (lane == kWave - 1) s_wsum[wave] = incl;
   __syncthreads();
-  unsigned run = bases[pass * kRsMaxRadix + d] + incl - mine;
-  for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+  unsigned run = incl - mine, all = 0;
+  for (unsigned w = 0; w < kRsWaves; ++w) {
+    const unsigned s = s_wsum[w];
+    if (w < wave) run += s;
+    all += s;
+  }
+  if (tid == 0) totals[pass * kRsMaxRadix + d] = all;
 #pragma unroll
   for (unsigned j = 0; j < kMaxPer; ++j) {
     if (j < per && first + j < num_chunks) row[first + j] = run;
@@ -356,15 +324,77 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   }
 }
 
-// ---- ranking by LDS atomics: the property it rests on, checked on the device before it is used --------------------
+// ---- 4-bit, per pass: ONE workgroup turns cnt[chunk][16] into off[chunk][16] (global start of the chunk's keys of every
+// digit) and clears the matrix the pass's scatter accumulates the next pass's counts into -----------------------------
+__global__ __launch_bounds__(1024) void rs_scan4_kernel(int pass, const RsHeader *hdr, unsigned *cnt2, unsigned *__restrict__ off,
+                                                        size_t num_chunks) {
+  constexpr int kW = 1024 / kWave;
+  __shared__ unsigned s_w[kW][16];  // per-wave digit sums, then exclusive over the waves
+  __shared__ unsigned s_base[16];
+  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+  if (!rs_varies<4>(varying, pass)) return;
+  const unsigned par = rs_parity<4>(varying, pass);
+  const u32x4 *__restrict__ cur = reinterpret_cast<const u32x4 *>(cnt2 + static_cast<size_t>(par) * num_chunks * 16);
+  u32x4 *next = reinterpret_cast<u32x4 *>(cnt2 + static_cast<size_t>(par ^ 1u) * num_chunks * 16);
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  unsigned v[16], incl[16];
+  const bool live = tid < num_chunks;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32x4 x = live ? cur[static_cast<size_t>(tid) * 4 + q] : u32x4{0, 0, 0, 0};
+    v[q * 4 + 0] = x.x, v[q * 4 + 1] = x.y, v[q * 4 + 2] = x.z, v[q * 4 + 3] = x.w;
+    if (live) next[static_cast<size_t>(tid) * 4 + q] = u32x4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    incl[d] = wave_inclusive_scan(v[d]);
+    if (lane == kWave - 1) s_w[wave][d] = incl[d];
+  }
+  __syncthreads();
+  if (tid < 16) {  // digit tid: exclusive over the waves, digit total
+    unsigned run = 0;
+    for (int w = 0; w < kW; ++w) {
+      const unsigned t = s_w[w][tid];
+      s_w[w][tid] = run;
+      run += t;
+    }
+    // exclusive scan of the 16 totals inside the first 16 lanes of wave 0 (row_shr stays inside a 16-lane row)
+    unsigned x = run;
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);
+    s_base[tid] = x - run;
+  }
+  __syncthreads();
+  if (live) {
+    u32x4 *o = reinterpret_cast<u32x4 *>(off) + static_cast<size_t>(tid) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned r[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = q * 4 + e;
+        r[e] = s_base[d] + s_w[wave][d] + incl[d] - v[d];
+      }
+      o[q] = u32x4{r[0], r[1], r[2], r[3]};
+    }
+  }
+}
+
+// ---- ranking by LDS atomics: the property it rests on, and how it is watched -------------------------------------------
 // rank = atomicAdd(&count[wave][digit], 1) replaces the BITS ballots of match_digit (8-bit digits: ~55 of the scatter's
 // ~100 vector instructions per 64 keys; the kernel is VALU-bound) by one ds_add_rtn_u32.  An LSD sort needs a STABLE
 // rank.  Between instructions the LDS keeps a wave's operations in issue order; INSIDE one instruction the rank is
 // stable iff lanes that hit the same counter get their return values in ascending lane order.  gfx950 does that (the
-// LDS serialises the lanes of a conflicting access lowest lane first) but the ISA manual does not promise it, so the
-// first sort on a device runs this kernel — every lane compares what the atomic returned with the count the ballots
-// predict, over dense, sparse, skewed and partially masked digit patterns on every CU — and the sort only ranks by
-// atomics where no lane ever disagreed; otherwise it keeps the ballots (DBHIP_RS_RANK=ballot|atomic overrides).
+// LDS serialises the lanes of a conflicting access lowest lane first) but the ISA manual does not promise it.  Three
+// guards: (1) the atomic ranking is the default only on an allow-listed architecture (gfx950); (2) EVERY tile of EVERY
+// call checks the invariant the ranking exists for — after k stable passes a tile re-ordered by digit k is sorted by
+// its low (k+1) digits, so thread p compares its key with its left neighbour's under that mask while it writes the
+// tile out; a violation sets DBHIP_DEV_RANK_ORDER in the workspace's status word (it also catches a damaged earlier
+// pass); (3) dbhip_radix_sort_prepare() runs the kernel below — every lane compares what the atomic returned with the
+// count the ballots predict, over dense, sparse, skewed and partially masked digit patterns on every CU — and pins
+// the ranking to what it saw.  The sort entry points themselves never synchronise (DBHIP_RS_RANK=ballot|atomic overrides).
 __global__ __launch_bounds__(kRsThreads) void rs_rank_selftest_kernel(unsigned *mismatches) {
   __shared__ unsigned s_cnt[kRsWaves][256];
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -392,10 +422,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_rank_selftest_kernel(unsigned *
   if (bad) atomicAdd(mismatches, bad);
 }
 
-// true: the scatter may rank by LDS atomics on the current device.  Decided once per device (a launch and a stream
-// synchronisation on the caller's stream, inside the first sort); while the stream is being captured into a graph
-// and nothing is known yet, the answer is "ballots" and nothing is cached.  scratch: one device word.
-std::atomic<int> g_rank_verdict[64];  // per device: 0 unknown, 1 atomics, 2 ballots
+std::atomic<int> g_rank_verdict[64];  // per device, set by dbhip_radix_sort_prepare: 0 not run, 1 atomics, 2 ballots
 int rank_forced() {
   static const int forced = [] {
     const char *e = std::getenv("DBHIP_RS_RANK");
@@ -403,36 +430,44 @@ int rank_forced() {
   }();
   return forced;
 }
-bool rank_by_lds_atomics(hipStream_t s, unsigned *scratch) {
-  std::atomic<int> *verdict = g_rank_verdict;
+// true: the scatter ranks by LDS atomics on the current device.  No device work, no synchronisation.
+bool rank_by_lds_atomics() {
   const int forced = rank_forced();
   if (forced) return forced == 1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  const int known = verdict[dev].load(std::memory_order_acquire);
+  const int known = g_rank_verdict[dev].load(std::memory_order_acquire);
   if (known) return known == 1;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
-  unsigned host = 1;
-  const DeviceInfo &info = current_device_info();
-  if (fill_async(scratch, 0, sizeof(unsigned), s) != hipSuccess) return false;
-  hipLaunchKernelGGL(rs_rank_selftest_kernel, dim3(info.ok ? info.cus * 2 : 512), dim3(kRsThreads), 0, s, scratch);  // ~50 us, once
-  if (hipMemcpyAsync(&host, scratch, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess)
-    return false;
-  verdict[dev].store(host == 0 ? 1 : 2, std::memory_order_release);
-  return host == 0;
+  return current_device_info().gfx950;
+}
+unsigned rank_fault_injection() {  // test hook: one swapped pair inside a digit run of the first tile, every pass
+  static const unsigned on = [] { const char *e = std::getenv("DBHIP_RS_INJECT_UNSTABLE"); return e && e[0] == '1' ? 1u : 0u; }();
+  return on;
 }
 
-// ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
+// ---- per pass: stable scatter of every chunk ---------------------------------------------------------------------
+// LDS of the scatter kernel, handed to the tile routine
+template <int BITS>
+struct RsLds {
+  unsigned (*cnt)[1 << BITS];  // per-wave digit counts, then wave-exclusive offsets
+  unsigned *dexcl;             // tile-local exclusive offset of each digit
+  unsigned *goff;              // global offset of a digit minus its local offset
+  unsigned *wsum;
+  unsigned *keys;
+  unsigned *bnd;               // 4-bit: first output position of digit d that belongs to the SECOND destination chunk
+  unsigned *h2;                // 4-bit: [2][16][16] next-digit counts per (destination chunk, digit)
+};
+
 // One tile of the scatter: stable rank inside each wave, digit offsets across waves, re-order through LDS, write out
 // in digit order.  FULL = the tile holds kRsTile keys: no per-key bounds checks (the kernel is VALU-bound — about 100
-// vector instructions per 64 keys, 80 % of the issue slots at 2^24 keys by the SQ counters).
+// vector instructions per 64 keys with ballots, 80 % of the issue slots at 2^24 keys by the SQ counters).
+// shift2 >= 0 (4-bit only): count the digit at shift2 of every key against its destination chunk (see the file header).
+// Returns nonzero if the tile, re-ordered by its digit, was not sorted by its low (shift + BITS) bits.
 template <int BITS, bool FULL, bool ARANK>
-__device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src, unsigned *__restrict__ dst,
-                                                size_t tile_base, unsigned valid_in_tile, int shift, unsigned xor_mask,
-                                                unsigned &running, unsigned (*s_cnt)[1 << BITS], unsigned *s_dexcl,
-                                                unsigned *s_goff, unsigned *s_wsum, unsigned *s_keys) {
+__device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__ src, unsigned *__restrict__ dst,
+                                                    size_t tile_base, unsigned valid_in_tile, int shift, int shift2,
+                                                    unsigned xor_mask, unsigned low_mask, bool inject, unsigned &running,
+                                                    const RsLds<BITS> &L) {
   constexpr int kRadix = 1 << BITS;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const unsigned wave_first = wave * kRsWaveKeys + lane;
@@ -442,7 +477,7 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
     const unsigned idx = wave_first + j * kWave;
     key[j] = (FULL || idx < valid_in_tile) ? src[tile_base + idx] : 0xFFFFFFFFu;
   }
-  for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
+  for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&L.cnt[0][0])[i] = 0;
   __syncthreads();
 
   // ---- stable rank of every key among the keys of its wave with the same digit
@@ -451,8 +486,8 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
   for (int j = 0; j < kRsKpt; ++j) {
     const bool valid = FULL || wave_first + j * kWave < valid_in_tile;
     const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-    if (ARANK) {  // one returning LDS atomic: see rank_by_lds_atomics() for why this is a stable rank
-      rank[j] = valid ? atomicAdd(&s_cnt[wave][d], 1u) : 0u;
+    if (ARANK) {  // one returning LDS atomic: see rs_rank_selftest_kernel for why this is a stable rank
+      rank[j] = valid ? atomicAdd(&L.cnt[wave][d], 1u) : 0u;
       continue;
     }
     LaneMask m = match_digit<BITS>(d);
@@ -462,9 +497,9 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
       m.hi &= static_cast<unsigned>(v >> 32);
     }
     const unsigned prior = lanes_before(m);
-    const unsigned c = s_cnt[wave][d];  // same address inside a digit group: LDS broadcast
+    const unsigned c = L.cnt[wave][d];  // same address inside a digit group: LDS broadcast
     rank[j] = c + prior;
-    if (valid && prior == 0) s_cnt[wave][d] = c + lanes_in(m);  // group leader
+    if (valid && prior == 0) L.cnt[wave][d] = c + lanes_in(m);  // group leader
   }
   __syncthreads();
 
@@ -473,19 +508,19 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
   if (tid < kRadix) {
 #pragma unroll
     for (int w = 0; w < kRsWaves; ++w) {
-      const unsigned c = s_cnt[w][tid];
-      s_cnt[w][tid] = tile_count;
+      const unsigned c = L.cnt[w][tid];
+      L.cnt[w][tid] = tile_count;
       tile_count += c;
     }
   }
   const unsigned incl = wave_inclusive_scan(tile_count);
-  if (lane == kWave - 1) s_wsum[wave] = incl;
+  if (lane == kWave - 1) L.wsum[wave] = incl;
   __syncthreads();
   unsigned dexcl = incl - tile_count;
-  for (unsigned w = 0; w < wave; ++w) dexcl += s_wsum[w];
+  for (unsigned w = 0; w < wave; ++w) dexcl += L.wsum[w];
   if (tid < kRadix) {
-    s_dexcl[tid] = dexcl;
-    s_goff[tid] = running - dexcl;
+    L.dexcl[tid] = dexcl;
+    L.goff[tid] = running - dexcl;
     running += tile_count;
   }
   __syncthreads();
@@ -495,47 +530,82 @@ __device__ __forceinline__ void rs_scatter_tile(const unsigned *__restrict__ src
   for (int j = 0; j < kRsKpt; ++j) {
     if (FULL || wave_first + j * kWave < valid_in_tile) {
       const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-      s_keys[s_dexcl[d] + s_cnt[wave][d] + rank[j]] = key[j];
+      L.keys[L.dexcl[d] + L.cnt[wave][d] + rank[j]] = key[j];
     }
   }
   __syncthreads();
+  if (inject) {  // test hook (uniform): swap the first neighbours that share the digit and differ below it
+    if (tid == 0)
+      for (unsigned p = 0; p + 1 < valid_in_tile && p < 4096; ++p) {
+        const unsigned a = L.keys[p] ^ xor_mask, b = L.keys[p + 1] ^ xor_mask;
+        if (((a ^ b) >> shift & (kRadix - 1)) == 0 && ((a ^ b) & low_mask) != 0) {
+          const unsigned t = L.keys[p];
+          L.keys[p] = L.keys[p + 1];
+          L.keys[p + 1] = t;
+          break;
+        }
+      }
+    __syncthreads();
+  }
 
   // ---- write out in digit order: consecutive lanes -> consecutive addresses inside a digit run
+  unsigned bad = 0;
 #pragma unroll
   for (int k = 0; k < kRsKpt; ++k) {
     const unsigned p = k * kRsThreads + tid;
     if (FULL || p < valid_in_tile) {
-      const unsigned kk = s_keys[p];
-      const unsigned d = ((kk ^ xor_mask) >> shift) & (kRadix - 1);
-      dst[s_goff[d] + p] = kk;
+      const unsigned kk = L.keys[p];
+      const unsigned kx = kk ^ xor_mask;
+      // the tile as it now lies in LDS must be sorted by its low (shift + BITS) bits (stable ranking, here and in
+      // every earlier pass): my left neighbour's may not exceed mine
+      const unsigned left = L.keys[p ? p - 1 : 0] ^ xor_mask;
+      bad |= (left & low_mask) > (kx & low_mask) ? 1u : 0u;
+      const unsigned d = (kx >> shift) & (kRadix - 1);
+      const unsigned pos = L.goff[d] + p;
+      dst[pos] = kk;
+      if (BITS == 4 && shift2 >= 0) {
+        const unsigned d2 = (kx >> shift2) & (kRadix - 1);
+        atomicAdd(&L.h2[((pos >= L.bnd[d] ? 16u : 0u) + d) * 16u + d2], 1u);
+      }
     }
   }
   __syncthreads();
+  return bad;
 }
 
 template <int BITS, bool ARANK>
-__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n,
-                                                                         int pass, unsigned xor_mask,
-                                                                         const RsHeader *hdr,
+__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_kernel(unsigned *keys, unsigned *tmp, size_t n, int pass,
+                                                                         unsigned xor_mask, RsHeader *hdr,
                                                                          const unsigned *__restrict__ offsets,
-                                                                         const unsigned *__restrict__ bases,
-                                                                         size_t tiles_per_chunk, size_t num_chunks) {
-  // bases != nullptr: `offsets` still holds the raw per-chunk counts and this kernel sums its own prefix (few
-  // chunks: the separate scan kernel would only add a dependent launch, ~5 us each at small sizes)
+                                                                         const unsigned *__restrict__ totals,
+                                                                         unsigned *next_counts, unsigned fused_scan,
+                                                                         unsigned inject, size_t tiles_per_chunk,
+                                                                         size_t num_chunks) {
+  // 8-bit: offsets = counts[256][chunks] after rs_chunk_scan (fused_scan: still the raw counts, and this kernel sums its
+  //        own prefix and the totals — few chunks: the separate scan kernel would only add a dependent launch, ~5 us each
+  //        at small sizes), totals = this pass's row totals.
+  // 4-bit: offsets = off[chunks][16] of rs_scan4 (global positions), next_counts = cnt2 (both matrices).
   constexpr int kRadix = 1 << BITS;
-  __shared__ unsigned s_cnt[kRsWaves][kRadix];  // per-wave digit counts, then wave-exclusive offsets
-  __shared__ unsigned s_dexcl[kRadix];          // tile-local exclusive offset of each digit
-  __shared__ unsigned s_goff[kRadix];           // global offset of a digit minus its local offset
+  __shared__ unsigned s_cnt[kRsWaves][kRadix];
+  __shared__ unsigned s_dexcl[kRadix];
+  __shared__ unsigned s_goff[kRadix];
   __shared__ unsigned s_wsum[kRsWaves];
   __shared__ unsigned s_keys[kRsTile];
+  __shared__ unsigned s_bnd[BITS == 4 ? 16 : 1], s_c0[BITS == 4 ? 16 : 1];
+  __shared__ unsigned s_h2[BITS == 4 ? 512 : 1];
+  const RsLds<BITS> L{s_cnt, s_dexcl, s_goff, s_wsum, s_keys, s_bnd, s_h2};
 
-  const RsPass plan = hdr->pass[pass];
-  if (plan.skip) return;  // uniform over the grid
-  const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
-  unsigned *__restrict__ dst = plan.src_is_tmp ? keys : tmp;
+  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+  if (!rs_varies<BITS>(varying, pass)) return;  // uniform over the grid
+  const unsigned par = rs_parity<BITS>(varying, pass);
+  const unsigned *__restrict__ src = par ? tmp : keys;
+  unsigned *__restrict__ dst = par ? keys : tmp;
   const int shift = pass * BITS;
+  const int next = BITS == 4 ? rs_next_pass<BITS>(varying, pass) : -1;
+  const int shift2 = next >= 0 ? next * BITS : -1;
+  const unsigned low_mask = shift + BITS >= 32 ? 0xFFFFFFFFu : (1u << (shift + BITS)) - 1u;
 
-  const unsigned tid = threadIdx.x;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   // XCD-aware chunk order (speed only): workgroups go to the 8 XCDs round-robin by blockIdx; XCD x takes the x-th
   // eighth of the chunks, so neighbouring chunks — whose digit runs are neighbours in the output and share the
   // partial lines at their ends — are written through the same L2.
@@ -548,14 +618,40 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   last_tile = last_tile < total_tiles ? last_tile : total_tiles;
   // digit owners keep the chunk's running global offset of their digit in a register
   unsigned running = 0;
-  if (tid < kRadix) {
-    if (bases) {
-      running = bases[pass * kRsMaxRadix + tid];
+  if (BITS == 8) {
+    unsigned total = 0;
+    if (tid < kRadix) {
       const unsigned *row = offsets + static_cast<size_t>(tid) * num_chunks;
-      for (size_t c = 0; c < chunk; ++c) running += row[c];
-    } else {
-      running = offsets[static_cast<size_t>(tid) * num_chunks + chunk];
+      if (fused_scan) {
+        for (size_t c = 0; c < num_chunks; ++c) {
+          const unsigned v = row[c];
+          if (c < chunk) running += v;
+          total += v;
+        }
+      } else {
+        running = row[chunk];
+        total = totals[pass * kRsMaxRadix + tid];
+      }
     }
+    // digit base = exclusive scan of the 256 totals (threads 0..255 = waves 0..3)
+    const unsigned incl = wave_inclusive_scan(total);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = incl - total;
+    for (unsigned w = 0; w < wave; ++w) base += s_wsum[w];
+    running += base;
+    __syncthreads();  // s_wsum is reused by the tiles
+  } else {
+    const size_t chunk_keys = tiles_per_chunk * kRsTile;
+    if (tid < kRadix) {
+      running = offsets[chunk * kRadix + tid];
+      const unsigned c0 = static_cast<unsigned>(running / chunk_keys);
+      const unsigned long long bnd = static_cast<unsigned long long>(c0 + 1u) * chunk_keys;
+      s_c0[tid] = c0;
+      s_bnd[tid] = bnd > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<unsigned>(bnd);
+    }
+    for (int i = tid; i < 512; i += kRsThreads) s_h2[i] = 0;
+    // (the first tile's barriers order these LDS writes before their first use in its write-out loop)
   }
 
   // (prefetching the next tile's keys into a second register set was measured: it needs 3 waves/SIMD
@@ -564,15 +660,28 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   //  for right before the current tile's stores, carried across the loop through an opaque v_mov so that no vmcnt(0)
   //  sits at the loop head — with 16 and 8 keys per lane at 3-6 waves per SIMD: 288-360 us against 272 us for one
   //  chunk per workgroup.  This kernel is not waiting for its loads.)
+  unsigned bad = 0;
   for (size_t tile = first_tile; tile < last_tile; ++tile) {
     const size_t tile_base = tile * kRsTile;
     const unsigned valid_in_tile = static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
+    const bool inj = inject != 0 && tile == 0;
     if (valid_in_tile == kRsTile)  // every tile but the input's last one
-      rs_scatter_tile<BITS, true, ARANK>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
-                                  s_wsum, s_keys);
+      bad |= rs_scatter_tile<BITS, true, ARANK>(src, dst, tile_base, valid_in_tile, shift, shift2, xor_mask, low_mask, inj,
+                                                running, L);
     else
-      rs_scatter_tile<BITS, false, ARANK>(src, dst, tile_base, valid_in_tile, shift, xor_mask, running, s_cnt, s_dexcl, s_goff,
-                                   s_wsum, s_keys);
+      bad |= rs_scatter_tile<BITS, false, ARANK>(src, dst, tile_base, valid_in_tile, shift, shift2, xor_mask, low_mask, inj,
+                                                 running, L);
+  }
+  if (bad) atomicOr(&hdr->status, DBHIP_DEV_RANK_ORDER);
+  if (BITS == 4 && shift2 >= 0) {
+    // the next pass's counts: table entry (w, d, d') belongs to chunk c0[d] + w of the next pass (the tiles' last barrier
+    // has ordered the table's atomics before these reads); 16 consecutive lanes add to 64 contiguous bytes
+    unsigned *nc = next_counts + static_cast<size_t>(par ^ 1u) * num_chunks * 16;
+    for (unsigned i = tid; i < 512; i += kRsThreads) {
+      const unsigned v = s_h2[i];
+      const size_t c = static_cast<size_t>(s_c0[(i >> 4) & 15u]) + (i >> 8);
+      if (v && c < num_chunks) atomicAdd(&nc[c * 16 + (i & 15u)], v);
+    }
   }
 }
 
@@ -582,8 +691,8 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
 // scatter kernel does and re-orders them through LDS; passes whose digit is constant over the input are skipped
 // on a workgroup-uniform vote; the result is written back to `keys`.
 template <int BITS, bool ARANK>
-__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kernel(unsigned *keys, unsigned n,
-                                                                                  unsigned xor_mask) {
+__global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kernel(unsigned *keys, unsigned n, unsigned xor_mask,
+                                                                                  unsigned *status) {
   constexpr int kRadix = 1 << BITS;
   constexpr int kPasses = 32 / BITS;
   __shared__ unsigned s_cnt[kRsWaves][kRadix];
@@ -615,9 +724,11 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
   __syncthreads();
   const unsigned varying = s_or ^ s_and;  // bits that differ somewhere in the input
 
+  unsigned bad = 0;
   for (int pass = 0; pass < kPasses; ++pass) {
     const int shift = pass * BITS;
     if (((varying >> shift) & (kRadix - 1)) == 0) continue;  // constant digit: the pass is the identity
+    const unsigned low_mask = shift + BITS >= 32 ? 0xFFFFFFFFu : (1u << (shift + BITS)) - 1u;
     for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     unsigned rank[kRsKpt];
@@ -667,9 +778,12 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
     for (int j = 0; j < kRsKpt; ++j) {
       const unsigned idx = wave_first + j * kWave;
       key[j] = idx < n ? s_keys[idx] : 0xFFFFFFFFu;
+      if (idx < n && idx > 0)  // the same order check as in rs_scatter_tile
+        bad |= ((s_keys[idx - 1] ^ xor_mask) & low_mask) > ((key[j] ^ xor_mask) & low_mask) ? 1u : 0u;
     }
     __syncthreads();
   }
+  if (bad) atomicOr(status, DBHIP_DEV_RANK_ORDER);
 #pragma unroll
   for (int j = 0; j < kRsKpt; ++j) {
     const unsigned idx = wave_first + j * kWave;
@@ -677,10 +791,10 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
   }
 }
 
-__global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__restrict__ keys,
-                                                                 const unsigned *__restrict__ tmp,
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__restrict__ keys, const unsigned *__restrict__ tmp,
                                                                  size_t n, const RsHeader *hdr) {
-  if (!hdr->final_in_tmp) return;
+  if (!rs_parity<BITS>(hdr->or_bits & hdr->nor_bits, 32 / BITS)) return;  // an even number of passes ran
   const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
   const size_t n4 = n / 4;
   const u32x4 *s4 = reinterpret_cast<const u32x4 *>(tmp);
@@ -691,58 +805,85 @@ __global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__res
 }
 
 template <int BITS>
+size_t rs_workspace_bytes(const RsGeometry &g) {
+  return align_up(BITS == 8 ? kRsCountsOff + sizeof(unsigned) * 256 * g.chunks
+                            : kRs4CntOff + sizeof(unsigned) * 16 * g.chunks * 3,
+                  kWsAlign);
+}
+
+template <int BITS>
 int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, void *workspace,
                     hipStream_t s, const DeviceInfo &dev) {
   constexpr int kPasses = 32 / BITS;
-  constexpr int kRadix = 1 << BITS;
   const RsGeometry g = rs_geometry(n, BITS);
   char *base = static_cast<char *>(workspace);
   RsHeader *hdr = reinterpret_cast<RsHeader *>(base);
-  unsigned *totals = reinterpret_cast<unsigned *>(base + kRsTotalsOff);
-  unsigned *bases = reinterpret_cast<unsigned *>(base + kRsBasesOff);
-  unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
 
-  const bool arank = rank_by_lds_atomics(s, totals);  // (totals is cleared below)
+  const bool arank = rank_by_lds_atomics();
+  const unsigned inject = rank_fault_injection();
   if (n <= static_cast<size_t>(kRsTile)) {  // one tile: one workgroup, one launch (+ the status word)
     const hipError_t e0 = fill_async(workspace, 0, kWsHeader, s);
     if (e0 != hipSuccess) return static_cast<int>(e0);
     if (arank)
       hipLaunchKernelGGL((rs_single_tile_kernel<BITS, true>), dim3(1), dim3(kRsThreads), 0, s, keys,
-                         static_cast<unsigned>(n), xor_mask);
+                         static_cast<unsigned>(n), xor_mask, &hdr->status);
     else
       hipLaunchKernelGGL((rs_single_tile_kernel<BITS, false>), dim3(1), dim3(kRsThreads), 0, s, keys,
-                         static_cast<unsigned>(n), xor_mask);
+                         static_cast<unsigned>(n), xor_mask, &hdr->status);
     return launch_status();
   }
-  hipError_t e = fill_async(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)
+  hipError_t e = fill_async(workspace, 0, kWsHeader, s);
   if (e != hipSuccess) return static_cast<int>(e);
 
-  const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * 4;
-  const unsigned hgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
-  const size_t hist_groups = (g.chunks + rs_hist_cpw<BITS>() - 1) / rs_hist_cpw<BITS>();
+  const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
+  const unsigned fgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+  constexpr int kCpw = rs_hist_cpw<BITS>();
+  const size_t hist_groups = (g.chunks + kCpw - 1) / kCpw;
   const unsigned hist_grid = static_cast<unsigned>(hist_groups < cap ? hist_groups : cap);
-  hipLaunchKernelGGL((rs_histogram_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n,
-                     xor_mask, totals, counts, g.tiles_per_chunk, g.chunks);
-  hipLaunchKernelGGL((rs_plan_kernel<BITS>), dim3(1), dim3(kRsThreads), 0, s, n, hdr, totals, bases);
   const unsigned cgrid = static_cast<unsigned>(g.chunks);
-  const bool fused_scan = g.chunks <= kRsFusedScanChunks;
-  for (int p = 0; p < kPasses; ++p) {
-    if (p > 0)  // pass 0's chunk counts came with the up-front histogram
-      hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS>), dim3((cgrid + rs_hist_cpw<BITS>() - 1) / rs_hist_cpw<BITS>()), dim3(kRsThreads), 0, s, keys, tmp, n, p, xor_mask,
-                         hdr, counts, g.tiles_per_chunk, g.chunks);
-    if (!fused_scan)
-      hipLaunchKernelGGL((rs_chunk_scan_kernel<BITS>), dim3(kRadix), dim3(kRsThreads), 0, s, p, hdr, bases, counts,
-                         g.chunks);
-    const unsigned *fused_bases = fused_scan ? bases : static_cast<const unsigned *>(nullptr);
-    if (arank)
-      hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, true>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys,
-                         tmp, n, p, xor_mask, hdr, counts, fused_bases, g.tiles_per_chunk, g.chunks);
-    else
-      hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, false>), dim3((cgrid + 7) / 8 * 8), dim3(kRsThreads), 0, s, keys,
-                         tmp, n, p, xor_mask, hdr, counts, fused_bases, g.tiles_per_chunk, g.chunks);
+  const unsigned sgrid = (cgrid + 7) / 8 * 8;
+  if (BITS == 8) {
+    unsigned *totals = reinterpret_cast<unsigned *>(base + kRsTotalsOff);
+    unsigned *counts = reinterpret_cast<unsigned *>(base + kRsCountsOff);
+    const unsigned fused_scan = g.chunks <= kRsFusedScanChunks ? 1u : 0u;
+    hipLaunchKernelGGL((rs_upfront_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n, xor_mask, hdr, counts,
+                       g.tiles_per_chunk, g.chunks);
+    for (int p = 0; p < kPasses; ++p) {
+      if (p > 0)  // pass 0's chunk counts came with the up-front read
+        hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS, false>), dim3(static_cast<unsigned>(hist_groups)), dim3(kRsThreads), 0, s,
+                           keys, tmp, n, p, xor_mask, hdr, counts, g.tiles_per_chunk, g.chunks);
+      if (!fused_scan)
+        hipLaunchKernelGGL(rs_chunk_scan_kernel, dim3(256), dim3(kRsThreads), 0, s, p, hdr, totals, counts, g.chunks);
+      if (arank)
+        hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, true>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                           xor_mask, hdr, counts, totals, static_cast<unsigned *>(nullptr), fused_scan, inject,
+                           g.tiles_per_chunk, g.chunks);
+      else
+        hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, false>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                           xor_mask, hdr, counts, totals, static_cast<unsigned *>(nullptr), fused_scan, inject,
+                           g.tiles_per_chunk, g.chunks);
+    }
+  } else {
+    unsigned *cnt2 = reinterpret_cast<unsigned *>(base + kRs4CntOff);
+    unsigned *off = cnt2 + 2 * 16 * g.chunks;
+    hipLaunchKernelGGL((rs_upfront_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n, xor_mask, hdr, cnt2,
+                       g.tiles_per_chunk, g.chunks);
+    hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS, true>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, 0, xor_mask, hdr,
+                       cnt2, g.tiles_per_chunk, g.chunks);
+    for (int p = 0; p < kPasses; ++p) {
+      hipLaunchKernelGGL(rs_scan4_kernel, dim3(1), dim3(1024), 0, s, p, hdr, cnt2, off, g.chunks);
+      if (arank)
+        hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, true>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                           xor_mask, hdr, off, static_cast<const unsigned *>(nullptr), cnt2, 0u, inject, g.tiles_per_chunk,
+                           g.chunks);
+      else
+        hipLaunchKernelGGL((rs_chunk_scatter_kernel<BITS, false>), dim3(sgrid), dim3(kRsThreads), 0, s, keys, tmp, n, p,
+                           xor_mask, hdr, off, static_cast<const unsigned *>(nullptr), cnt2, 0u, inject, g.tiles_per_chunk,
+                           g.chunks);
+    }
   }
-  hipLaunchKernelGGL(rs_finalize_kernel, dim3(hgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
+  hipLaunchKernelGGL((rs_finalize_kernel<BITS>), dim3(fgrid), dim3(kRsThreads), 0, s, keys, tmp, n, hdr);
   return launch_status();
 }
 
@@ -774,16 +915,37 @@ using namespace dbhip;
 extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
   if (radix_bits != 4 && radix_bits != 8) return 0;
   const RsGeometry g = rs_geometry(n, radix_bits);
-  const size_t radix = static_cast<size_t>(1) << radix_bits;
-  return align_up(kRsCountsOff + sizeof(unsigned) * radix * g.chunks, kWsAlign);
+  return radix_bits == 8 ? rs_workspace_bytes<8>(g) : rs_workspace_bytes<4>(g);
 }
 
 extern "C" int dbhip_radix_sort_rank_mode(void) {
-  if (rank_forced()) return rank_forced() == 1;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-  const int v = g_rank_verdict[dev].load(std::memory_order_acquire);
-  return v == 0 ? -1 : (v == 1 ? 1 : 0);
+  if (!rank_forced() && (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)) return -1;
+  return rank_by_lds_atomics() ? 1 : 0;
+}
+
+extern "C" int dbhip_radix_sort_prepare(dbhip_stream_t stream) {
+  hipStream_t s = as_stream(stream);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DBHIP_ENODEVICE;
+  const DeviceInfo &info = current_device_info();
+  if (!info.ok) return DBHIP_ENODEVICE;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return DBHIP_EINVAL;
+  unsigned *scratch = nullptr;
+  unsigned host = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&scratch), kWsAlign);
+  if (e != hipSuccess) return static_cast<int>(e);
+  e = fill_async(scratch, 0, sizeof(unsigned), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rs_rank_selftest_kernel, dim3(info.cus * 2), dim3(kRsThreads), 0, s, scratch);  // ~50 us
+    e = hipMemcpyAsync(&host, scratch, sizeof(host), hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  if (e != hipSuccess) return static_cast<int>(e);
+  g_rank_verdict[dev].store(host == 0 ? 1 : 2, std::memory_order_release);
+  return rank_by_lds_atomics() ? 1 : 0;
 }
 
 extern "C" int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits,

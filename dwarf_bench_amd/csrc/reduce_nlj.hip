@@ -120,7 +120,11 @@ extern "C" int dbhip_reduce_sum_i32(const int32_t *src, size_t n, int32_t *out, 
   if (n == 0) return DBHIP_OK;
   const size_t tiles = (n + kRedTileInts - 1) / kRedTileInts;
   const size_t chunks = (tiles + kRedChunkTiles - 1) / kRedChunkTiles;
-  static const int wgs_per_cu = [] { const char *e = std::getenv("DBHIP_RED_WGS"); return e ? std::atoi(e) : 2; }();
+  static const int wgs_per_cu = [] {
+    const char *e = std::getenv("DBHIP_RED_WGS");  // experiment knob: workgroups per CU of the persistent grid
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= 16 ? v : 2;
+  }();
   const size_t cap = static_cast<size_t>(dev.cus) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(chunks < cap ? (chunks ? chunks : 1) : cap);
   size_t head = ((16 - (reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / 4;  // src is 4-byte aligned (int32)

@@ -84,6 +84,25 @@ struct Rank {
   size_t recv_r = 0, recv_s = 0;
   DevMem chk;                       // validator results / conservation sums
   ncclComm_t comm = nullptr;
+
+  Rank() = default;
+  Rank(const Rank &) = delete;
+  Rank &operator=(const Rank &) = delete;
+  // A rank owns its streams, events, pinned matrix and communicator: whatever had been created when an exception
+  // leaves the Engine constructor (or plan()) is released here, so the peers of a multi-process job see this rank's
+  // communicator go away instead of waiting for it until their watchdog fires.
+  ~Rank() {
+    (void)hipSetDevice(device);
+    if (compute) (void)hipStreamSynchronize(compute);
+    if (xchg) (void)hipStreamSynchronize(xchg);
+    if (comm) (void)ncclCommDestroy(comm);
+    for (hipEvent_t e : {ev_start, ev_part_r, ev_part_s, ev_cnt_r, ev_cnt_s, ev_x0, ev_xr, ev_xs, ev_build0, ev_build,
+                         ev_probe0, ev_done})
+      if (e) (void)hipEventDestroy(e);
+    if (compute) (void)hipStreamDestroy(compute);
+    if (xchg) (void)hipStreamDestroy(xchg);
+    if (mat_host) (void)hipHostFree(mat_host);
+  }
 };
 
 template <class T>
@@ -157,8 +176,31 @@ struct Engine::Impl {
     return k.mat_host[static_cast<size_t>(rel) * P * P + static_cast<size_t>(q) * P + r];
   }
 
+  // The gathered matrix decides every address and length of the exchange: before any send or receive is queued, check
+  // it against what the host knows without it — row q (what rank q sends) sums to rank q's shard size, hence the whole
+  // matrix to n and the column sums (what the ranks receive) to n as well.  A damaged gather (first contact with a
+  // real multi-GPU ncclAllGather) stops here with a message instead of scribbling over device memory.
+  void validate_matrix(const Rank &k, unsigned rel) const {
+    const size_t per = n / P;
+    uint64_t all = 0, cols = 0;
+    for (unsigned q = 0; q < P; ++q) {
+      uint64_t row = 0;
+      for (unsigned r = 0; r < P; ++r) row += cell(k, P, rel, q, r);
+      const uint64_t shard = (q == P - 1) ? n - static_cast<size_t>(q) * per : per;
+      if (row != shard)
+        fail("partitioned join: rank " + std::to_string(k.id) + " gathered a count matrix whose row " + std::to_string(q) +
+             " sums to " + std::to_string(row) + ", not to that rank's shard of " + std::to_string(shard) + " rows (relation " +
+             std::to_string(rel) + ")");
+      all += row;
+    }
+    for (unsigned r = 0; r < P; ++r)
+      for (unsigned q = 0; q < P; ++q) cols += cell(k, P, rel, q, r);
+    if (all != n || cols != n) fail("partitioned join: the gathered count matrix does not add up to the relation's row count");
+  }
+
   void size_receives(unsigned rel) {
     for (auto &k : ranks) {
+      validate_matrix(*k, rel);
       size_t total = 0;
       for (unsigned q = 0; q < P; ++q) total += cell(*k, P, rel, q, k->id);
       (rel == 0 ? k->recv_r : k->recv_s) = total;
@@ -204,8 +246,14 @@ struct Engine::Impl {
       uint32_t *dst_k = (rel == 0 ? me.rk : me.sk).as<uint32_t>();
       uint32_t *dst_r = (rel == 0 ? me.rr : me.sr).as<uint32_t>();
       uint64_t send_off = 0, recv_off = 0;
+      const uint64_t recv_total = rel == 0 ? me.recv_r : me.recv_s;
+      const uint64_t recv_cap = (rel == 0 ? me.rk : me.sk).bytes / 4;
       for (unsigned q = 0; q < P; ++q) {
         const uint64_t send_cnt = cell(me, P, rel, me.id, q), recv_cnt = cell(me, P, rel, q, me.id);
+        // (validate_matrix has run in size_receives: these cannot fire unless the pinned matrix changed since)
+        if (send_off + send_cnt > me.n_local || recv_off + recv_cnt > recv_total || recv_total > recv_cap)
+          fail("partitioned join: exchange segment outside its buffer");
+        static_assert(kPiece <= (1ull << 28), "one ncclSend/ncclRecv carries at most 2^28 elements (1 GiB)");
         if (rccl) {
           for (int col = 0; col < 2; ++col) {
             const uint32_t *s = (col ? src_r : src_k) + send_off;
@@ -328,19 +376,7 @@ Engine::Engine(size_t n_total, const Options &opts) : impl_(new Impl) {
 Engine::~Engine() {
   if (!impl_) return;
   Impl &m = *impl_;
-  for (auto &k : m.ranks) {
-    (void)hipSetDevice(k->device);
-    (void)hipStreamSynchronize(k->compute);
-    (void)hipStreamSynchronize(k->xchg);
-    if (k->comm) (void)ncclCommDestroy(k->comm);
-    for (hipEvent_t e : {k->ev_start, k->ev_part_r, k->ev_part_s, k->ev_cnt_r, k->ev_cnt_s, k->ev_x0, k->ev_xr, k->ev_xs,
-                         k->ev_build0, k->ev_build, k->ev_probe0, k->ev_done})
-      if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(k->compute);
-    (void)hipStreamDestroy(k->xchg);
-    if (k->mat_host) (void)hipHostFree(k->mat_host);
-  }
-  m.ranks.clear();
+  m.ranks.clear();  // ~Rank releases streams, events, pinned memory and the communicator
   (void)hipSetDevice(m.home);
 }
 
@@ -518,6 +554,8 @@ StepTimes Engine::step() {
     m.set(*k);
     t.partition = std::max(t.partition, span_us(k->ev_start, k->ev_part_s));
     t.exchange = std::max(t.exchange, span_us(k->ev_x0, k->ev_xs));
+    t.exchange_r = std::max(t.exchange_r, span_us(k->ev_x0, k->ev_xr));
+    t.exchange_s = std::max(t.exchange_s, span_us(k->ev_cnt_s, k->ev_xs));
     t.build = std::max(t.build, span_us(k->ev_build0, k->ev_build));
     t.probe = std::max(t.probe, span_us(k->ev_probe0, k->ev_done));
   }
@@ -702,9 +740,9 @@ extern "C" void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned w
     o.device = device;
     o.nccl_id = id128;
     o.direct_single = direct_single != 0;
-    auto *e = new pjoin::Engine(static_cast<size_t>(n_total), o);
-    e->plan();
-    return e;
+    auto e = std::make_unique<pjoin::Engine>(static_cast<size_t>(n_total), o);
+    e->plan();  // may throw: the engine (and with it the rank's communicator) is then released, not leaked
+    return e.release();
   } catch (const std::exception &ex) {
     std::cerr << "dbench_pjoin_create: " << ex.what() << std::endl;
     return nullptr;
@@ -716,7 +754,7 @@ extern "C" int dbench_pjoin_step(void *handle, double *times_us) {
   try {
     const pjoin::StepTimes t = static_cast<pjoin::Engine *>(handle)->step();
     if (times_us) {
-      const double v[6] = {t.total, t.partition, t.exchange, t.build, t.probe, t.until_build_done};
+      const double v[8] = {t.total, t.partition, t.exchange, t.build, t.probe, t.until_build_done, t.exchange_r, t.exchange_s};
       std::memcpy(times_us, v, sizeof(v));
     }
     return 0;

@@ -43,6 +43,9 @@ struct Options {
 struct StepTimes {  // microseconds; phases are device-event spans (max over the local ranks) and overlap by design
   double total = 0, partition = 0, exchange = 0, build = 0, probe = 0;
   double until_build_done = 0;  // host clock: step start -> the slowest local rank's build finished
+  // the two send/recv groups on their own (exchange stream events): R's pairs, then S's pairs — `exchange` above also
+  // spans the wait for partition S and the gather of S's counts between them
+  double exchange_r = 0, exchange_s = 0;
 };
 
 struct CheckReport {  // sums over the local ranks; a multi-process caller adds them up over its ranks
@@ -96,7 +99,7 @@ int dbench_pjoin_unique_id(char *out128);
 // every rank: device = local GPU index.  world == 1 needs no id.  Returns a handle or NULL (message on stderr).
 void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned world, int device, const char *id128,
                           int direct_single);
-// one join; times_us[6] = total, partition, exchange, build, probe, until_build_done.  0 on success.
+// one join; times_us[8] = total, partition, exchange, build, probe, until_build_done, exchange_r, exchange_s.  0 on success.
 int dbench_pjoin_step(void *handle, double *times_us);
 // after a step; words[16]: bad_pairs, bad_route, bad_rows, matches, recv_build, recv_probe, sent_rows,
 // conserved (over ALL ranks: collective call), sent_sum[4], recv_sum[4].  0 on success.

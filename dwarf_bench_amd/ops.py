@@ -12,7 +12,7 @@ import torch
 
 from . import _capi
 
-DEV_OK, DEV_SPIN_TIMEOUT, DEV_KEY_RANGE, DEV_TABLE_FULL = 0, 1, 2, 4
+DEV_OK, DEV_SPIN_TIMEOUT, DEV_KEY_RANGE, DEV_TABLE_FULL, DEV_RANK_ORDER = 0, 1, 2, 4, 8
 
 
 def _stream() -> int:
@@ -141,6 +141,15 @@ class RadixSort:
         fn = _capi.lib().dbhip_radix_sort_i32 if signed else _capi.lib().dbhip_radix_sort_u32
         _capi.check(fn(keys.data_ptr(), self.tmp.data_ptr(), self.n, self.bits, self.ws.data_ptr(), self.ws_bytes,
                        _stream()), "radix_sort")
+
+
+def radix_sort_prepare() -> int:
+    """optional calibration (synchronises the current stream once): device-side self-test of the LDS-atomic ranking;
+    returns the rank mode the sorts of this device use from now on (1 = LDS atomics, 0 = ballots)"""
+    rc = _capi.lib().dbhip_radix_sort_prepare(_stream())
+    if rc < 0 or rc > 1:
+        _capi.check(rc if rc else -1, "radix_sort_prepare")
+    return rc
 
 
 def radix_sort_(keys: torch.Tensor, signed: bool = False, radix_bits: int = 8) -> torch.Tensor:
@@ -428,19 +437,37 @@ class BitmaskTable:
 # ---------------------------------------------------------------------------------------------
 # exclusive prefix sum (scan/scan.cl:44-66, tests/scan_tests.cpp:14-21, dpl_wrapper.hpp:18-25)
 # ---------------------------------------------------------------------------------------------
+class ExclusiveScan:
+    """launch() is asynchronous; result() synchronises and raises on a device-side status (the single-launch path waits
+    on other workgroups with a bounded spin: DBHIP_DEV_SPIN_TIMEOUT means the prefix that was written is wrong)"""
+
+    def __init__(self, n: int, device="cuda"):
+        self.n = n
+        self.ws_bytes = _capi.lib().dbhip_exclusive_scan_u32_workspace_bytes(n)
+        self.ws = _ws(self.ws_bytes, device)
+        self.out = None
+
+    def launch(self, src: torch.Tensor, init: int = 0, out: torch.Tensor | None = None) -> None:
+        _need(src, torch.int32, "src")
+        assert src.numel() == self.n
+        if out is None:
+            out = torch.empty(max(self.n, 1), dtype=torch.int32, device=src.device)[: self.n]
+        _need(out, torch.int32, "out")
+        self.out = out
+        _capi.check(_capi.lib().dbhip_exclusive_scan_u32(src.data_ptr(), self.n, init & 0xFFFFFFFF, out.data_ptr(),
+                                                         self.ws.data_ptr(), self.ws_bytes, _stream()), "exclusive_scan_u32")
+
+    def result(self) -> torch.Tensor:
+        _check_status(self.ws, "exclusive_scan_u32")
+        return self.out
+
+
 def exclusive_scan(src: torch.Tensor, init: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
-    """out[0] = init, out[i] = init + src[0] + ... + src[i-1] (uint32 wrap-around); out may be src"""
-    _need(src, torch.int32, "src")
-    n = src.numel()
-    if out is None:
-        out = torch.empty(max(n, 1), dtype=torch.int32, device=src.device)[:n]
-    _need(out, torch.int32, "out")
-    lib = _capi.lib()
-    ws_bytes = lib.dbhip_exclusive_scan_u32_workspace_bytes(n)
-    ws = _ws(ws_bytes, src.device)
-    _capi.check(lib.dbhip_exclusive_scan_u32(src.data_ptr(), n, init & 0xFFFFFFFF, out.data_ptr(), ws.data_ptr(), ws_bytes,
-                                             _stream()), "exclusive_scan_u32")
-    return out
+    """out[0] = init, out[i] = init + src[0] + ... + src[i-1] (uint32 wrap-around); out may be src.  Checked: reads the
+    workspace's status word back (one synchronisation); use ExclusiveScan for asynchronous launches."""
+    plan = ExclusiveScan(src.numel(), src.device)
+    plan.launch(src, init, out)
+    return plan.result()
 
 
 # ---------------------------------------------------------------------------------------------

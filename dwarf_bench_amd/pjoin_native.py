@@ -12,7 +12,8 @@ from . import _capi
 _LIB = Path(__file__).resolve().parent / "_lib" / "libdbench.so"
 _lib = None
 
-STEP_FIELDS = ("total_us", "partition_us", "exchange_us", "build_us", "probe_us", "until_build_done_us")
+STEP_FIELDS = ("total_us", "partition_us", "exchange_us", "build_us", "probe_us", "until_build_done_us", "exchange_r_us",
+               "exchange_s_us")
 CHECK_FIELDS = ("bad_pairs", "bad_route", "bad_rows", "matches", "recv_build", "recv_probe", "sent_rows", "conserved")
 
 
@@ -58,7 +59,7 @@ class NativePartitionedJoin:
             raise _capi.DbhipError("dbench_pjoin_create failed (see stderr)")
 
     def step(self) -> dict:
-        t = (C.c_double * 6)()
+        t = (C.c_double * len(STEP_FIELDS))()
         if lib().dbench_pjoin_step(self._h, t) != 0:
             raise _capi.DbhipError("dbench_pjoin_step failed (see stderr)")
         return dict(zip(STEP_FIELDS, (float(x) for x in t)))

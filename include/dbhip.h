@@ -8,7 +8,8 @@
  * or any allocator handing out device memory, e.g. torch), `stream` is a hipStream_t passed as
  * void*, and every call is asynchronous on that stream.  Nothing here allocates, frees or
  * synchronises: scratch memory is caller-provided through the `*_workspace_bytes` queries, so a
- * call sequence can be captured into a hipGraph.
+ * call sequence can be captured into a hipGraph.  (One exception, named as such below:
+ * dbhip_radix_sort_prepare, an optional calibration call that is never needed inside a capture.)
  *
  * Return value: 0 on success, a negative DBHIP_E* code for argument errors detected on the host,
  * or a positive hipError_t if a launch failed.  Device-side failures (an out-of-range group key,
@@ -56,9 +57,12 @@ extern "C" {
 
 /* device-side status word values (dbhip_workspace_status) */
 #define DBHIP_DEV_OK 0u
-#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* dbhip_copy_if_lt_dense_i32: a chunk waited 2 s for its predecessors (never seen) */
+#define DBHIP_DEV_SPIN_TIMEOUT 1u  /* dbhip_copy_if_lt_dense_i32 and the single-launch path of dbhip_exclusive_scan_u32:
+                                      a chunk waited 2 s for its predecessors (never seen); the output is then wrong */
 #define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count, or the 0xFFFFFFFF sentinel as a join build key */
 #define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot */
+#define DBHIP_DEV_RANK_ORDER 8u    /* radix sort: a tile re-ordered by the pass's digit was not sorted by its lower digits —
+                                      the ranking was not stable (or an earlier pass was damaged); the output is wrong */
 
 typedef void *dbhip_stream_t; /* hipStream_t */
 
@@ -114,10 +118,19 @@ int dbhip_radix_sort_u32(uint32_t *keys, uint32_t *tmp, size_t n, int radix_bits
 /* signed order (the reference sorts `int`, sort/radix.cpp:8-12) */
 int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
-/* How the scatter ranks keys on the current device: 1 = one returning LDS atomic per key (used only where the
- * device-side self-test of the first sort saw same-address lanes served in lane order: gfx950 does), 0 = ballots,
- * -1 = not decided yet (no sort has run outside a graph capture).  DBHIP_RS_RANK=ballot|atomic overrides.        */
+/* How the scatter ranks keys on the current device: 1 = one returning LDS atomic per key, 0 = wave ballots, -1 = no
+ * device.  The atomic ranking is stable only if same-address lanes of one ds_add_rtn are served in lane order; gfx950
+ * does that, the ISA manual does not promise it.  It is therefore (a) the default on gfx950 only, (b) checked by EVERY
+ * tile of EVERY sort through the invariant it exists for (DBHIP_DEV_RANK_ORDER in the status word if a re-ordered tile
+ * is not sorted by its lower digits: about 2 % of the sort's time), and (c) pinned by dbhip_radix_sort_prepare.  The
+ * same ranking is used inside and outside graph captures.  DBHIP_RS_RANK=ballot|atomic overrides.                 */
 int dbhip_radix_sort_rank_mode(void);
+/* OPTIONAL calibration, the one call of this library that allocates (a scratch word) and SYNCHRONISES `stream`: runs
+ * a device-side self-test of the property above on every CU (~50 us) and pins the ranking of the current device to
+ * what it saw (atomics where no lane ever disagreed with the ballots' prediction, ballots otherwise).  Returns the
+ * resulting rank mode (1 / 0), DBHIP_EINVAL while `stream` is being captured, or an error code.  The sort entry
+ * points never call it and never synchronise.                                                                    */
+int dbhip_radix_sort_prepare(dbhip_stream_t stream);
 
 /* ---- dwarf 3: group-by hash aggregate, SUM ------------------------------------------------------
  * out[g] = sum of vals[i] over rows with keys[i] == g (uint32 wrap-around), g in [0, groups).

@@ -70,14 +70,16 @@ def test_exclusive_scan_aligned_in_place_init_and_streams():
     exp += np.uint32(123)
     outs = [torch.empty_like(src) for _ in range(4)]
     streams = [torch.cuda.Stream() for _ in range(4)]
+    plans = [ops.ExclusiveScan(n) for _ in range(4)]  # asynchronous launches, one workspace each
     torch.cuda.synchronize()
     for _ in range(3):
-        for o, st in zip(outs, streams):
+        for o, st, plan in zip(outs, streams, plans):
             with torch.cuda.stream(st):
-                ops.exclusive_scan(src, init=123, out=o)
+                plan.launch(src, init=123, out=o)
     torch.cuda.synchronize()
-    for o in outs:
-        assert np.array_equal(o.cpu().numpy().view(np.uint32), exp)
+    for o, plan in zip(outs, plans):
+        assert ops.workspace_status(plan.ws) == 0  # no bounded wait of the single-launch path ran out
+        assert np.array_equal(plan.result().cpu().numpy().view(np.uint32), exp)
     work = src.clone()
     ops.exclusive_scan(work, init=123, out=work)
     assert np.array_equal(work.cpu().numpy().view(np.uint32), exp)

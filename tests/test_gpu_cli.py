@@ -215,3 +215,29 @@ def test_partitioned_join_above_the_host_check_limit():
     r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", "8", "--iterations", "2", "--input_size", "16777216"],
              env={**os.environ, "DWARF_BENCH_VALIDATE_MAX": "1"})
     assert r.returncode == 0 and "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("gpus,tag,extra_env", [("8", "8_virtual_ranks", {}), ("1", "direct_one_gpu", {"DWARF_BENCH_PJOIN_DIRECT": "1"}),
+                                                ("1", "rccl_self_exchange", {})])
+def test_partitioned_join_baseline_config_5(gpus, tag, extra_env):
+    """BASELINE configs[4]: radix-partitioned hash join 2^30 x 2^30 (no reference counterpart).  The test box
+    has one GPU: --gpus 8 runs the eight ranks of the target configuration as virtual ranks sharing the device (every
+    rank partitions, exchanges and joins its 2^27-row shards — the per-rank work of the 8-GPU node, peer copies in
+    place of xGMI), --gpus 1 with DWARF_BENCH_PJOIN_DIRECT=1 is the one-GPU point of the scaling curve (plain local radix
+    join), --gpus 1 without it sends all 2^30 pairs of both relations through the RCCL send/recv group to the rank
+    itself (four pieces of 2^28 elements per column).  Host-side checks are off
+    (DWARF_BENCH_VALIDATE_MAX=1): Result::valid rests on the device-side checks (conservation, generator, routing,
+    per-row counts against the sorted build column).  The log is kept under gpurun_out/ (copies under profiles/)."""
+    import os
+    r = subprocess.run([str(LIB / "dwarf_bench"), "PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "1",
+                        "--input_size", "1073741824"], capture_output=True, text=True, timeout=900,
+                       env={**os.environ, "DWARF_BENCH_VALIDATE_MAX": "1", **extra_env})
+    log = Path(__file__).resolve().parents[1] / "gpurun_out"
+    log.mkdir(exist_ok=True)
+    (log / f"pjoin_2p30_{tag}.txt").write_text(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert f"{gpus} rank(s) on 1 GPU(s)" in r.stdout
+    for phase in ("Partition time:", "Exchange time:", "Local probe time:"):
+        assert r.stdout.count(phase) >= 1, r.stdout
+    assert r.stdout.count("Host duration:") == 1 and r.stdout.count("Build time:") == 1

@@ -87,6 +87,37 @@ def test_sort_graph_replay(n, bits):
         assert np.array_equal(keys.cpu().numpy().view(np.uint32), np.sort(host))
 
 
+def test_sort_captured_as_the_first_sort_of_a_process():
+    """The sort entry points never synchronise, and a captured sort ranks exactly like an eager one: in a fresh process
+    the very first sort is captured (no eager call before it — the module-load warm-up a torch capture needs is done
+    with another dwarf), the rank mode it reports is the LDS-atomic one, and replays give the oracle's order."""
+    import os, subprocess, sys
+    prog = (
+        "import numpy as np, torch\n"
+        "from dwarf_bench_amd import _capi, ops\n"
+        "from oracle import pyoracle as po\n"
+        "n = (1 << 20) + 3\n"
+        "ops.reduce_sum(ops.gen_uniform_u32(1024, 1, 0, 9)); torch.cuda.synchronize()  # loads the code object\n"
+        "keys = torch.empty(n, dtype=torch.int32, device='cuda')\n"
+        "plans = {b: ops.RadixSort(n, b) for b in (8, 4)}\n"
+        "for bits, plan in plans.items():\n"
+        "    g = torch.cuda.CUDAGraph()\n"
+        "    with torch.cuda.graph(g):\n"
+        "        plan.launch(keys)\n"
+        "    assert _capi.lib().dbhip_radix_sort_rank_mode() == 1\n"
+        "    for seed in (3, 4):\n"
+        "        host = po.gen_uniform_u32(n, seed, 0, 2**32 - 1)\n"
+        "        keys.copy_(torch.from_numpy(host.view(np.int32)))\n"
+        "        g.replay(); torch.cuda.synchronize()\n"
+        "        assert ops.workspace_status(plan.ws) == 0\n"
+        "        assert np.array_equal(keys.cpu().numpy().view(np.uint32), po.sort_u32(host)), (bits, seed)\n"
+        "print('captured first: ok')\n")
+    env = {k: v for k, v in os.environ.items() if k != "DBHIP_RS_RANK"}
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0 and "captured first: ok" in r.stdout, (r.stdout, r.stderr)
+
+
 @pytest.mark.parametrize("n,groups", [(100003, 64), (1 << 21, 65536)])
 def test_groupby_graph_replay(n, groups):
     from dwarf_bench_amd import ops

@@ -70,7 +70,7 @@ def test_join_vs_oracle_table_large():
 
 
 def test_join_baseline_config_2_26_properties():
-    """BASELINE configs[3]: 2^26 x 2^26.  Size-independent properties, checked on the device."""
+    """BASELINE configs[3]: 2^26 x 2^26.  Size-independent properties, checked on the device, then the oracle at full size."""
     from dwarf_bench_amd import ops
     n = 1 << 26
     build = ops.gen_uniform_u32(n, 42, 0, n - 1)
@@ -91,6 +91,17 @@ def test_join_baseline_config_2_26_properties():
     idx = torch.searchsorted(ub, up).clamp_(max=ub.numel() - 1)
     m = ub[idx] == up
     assert int(cnt.to(torch.int64).sum().item()) == int((cb[idx][m] * cp[m]).sum().item())
+    # the oracle on the WHOLE columns: the OmniSci table restated (omnisci_hashtable.hpp:80-192, 223-261) on all host
+    # cores gives every probe row's count and id list; counts compared row by row, id lists on a stride of rows
+    # (sorted inside the bucket: the reference compares size + membership, join/join_omnisci.cpp:31-45)
+    import os
+    hb, hp = build.cpu().numpy().view(np.uint32), probe.cpu().numpy().view(np.uint32)
+    opos, ocnt, oids = po.join_omnisci(hb, hp, threads=os.cpu_count() or 8)
+    hcnt, hpos, hids = (t.cpu().numpy().view(np.uint32) for t in (cnt, pos, ids))
+    assert np.array_equal(hcnt.astype(np.uint64), ocnt)
+    for i in range(0, n, 65537):
+        a = np.sort(hids[hpos[i]: hpos[i] + hcnt[i]]).astype(np.uint64)
+        assert np.array_equal(a, np.sort(oids[int(opos[i]): int(opos[i] + ocnt[i])])), i
 
 
 def test_ujoin_reference_fixture_shape(golden_dir):

@@ -81,9 +81,10 @@ def test_full_size_properties_2_28():
         again = ops.copy_if_lt(out.clone(), filt)  # idempotent
         assert torch.equal(again, out)
         del plan, out, again
-    # oracle on a bounded prefix of the same column
-    m = 1 << 22
-    assert np.array_equal(ops.copy_if_lt(src[:m], 5).cpu().numpy(), po.copy_if_lt(src[:m].cpu().numpy(), 5))
+    # the oracle (std::copy_if restated, scan/scan.cpp:12-17) on the WHOLE column, both filters
+    host = src.cpu().numpy()
+    for filt in (5, 1001):
+        assert np.array_equal(ops.copy_if_lt(src, filt).cpu().numpy(), po.copy_if_lt(host, filt)), filt
 
 
 @pytest.mark.parametrize("n", [(1 << 24) + 777, 250007, 77777])  # several chunks per workgroup, a few chunks, a single workgroup

@@ -66,12 +66,9 @@ def test_sort_2_24_baseline_config(bits):
     # idempotence: sorting sorted data changes nothing
     plan.launch(keys)
     assert torch.equal(keys.to(torch.int64) & 0xFFFFFFFF, exp)
-    # oracle on a bounded sample of the same column
-    m = 1 << 20
-    sample = ops.gen_uniform_u32(m, 42, 0, 2**32 - 1)
-    host = sample.cpu().numpy().view(np.uint32)
-    ops.radix_sort_(sample, radix_bits=bits)
-    assert np.array_equal(sample.cpu().numpy().view(np.uint32), po.sort_u32(host))
+    # the oracle (std::sort restated, sort/radix.cpp:8-12) on the WHOLE column
+    host = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1).cpu().numpy().view(np.uint32)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), po.sort_u32(host))
 
 
 def test_large_input_properties_2_30():
@@ -111,11 +108,14 @@ def test_empty_input_and_unaligned_column():
 
 
 def test_rank_by_lds_atomics_is_self_checked_and_both_rankings_agree():
-    """The scatter ranks with one returning LDS atomic per key where the device passed the lane-order self-test of its
-    first sort (gfx950 does); DBHIP_RS_RANK=ballot keeps the ballot ranking: both give the oracle's order, at sizes
-    on every path (single tile, fused scan, chunked) and both digit widths."""
+    """The scatter ranks with one returning LDS atomic per key on gfx950 (allow-list); dbhip_radix_sort_prepare runs the
+    device-side lane-order self-test and pins the mode to what it saw (gfx950 passes); DBHIP_RS_RANK=ballot keeps the
+    ballot ranking: both give the oracle's order, at sizes on every path (single tile, fused scan, chunked) and both
+    digit widths."""
     import os, subprocess, sys
     from dwarf_bench_amd import _capi, ops
+    assert _capi.lib().dbhip_radix_sort_rank_mode() == 1  # before any sort and without a self-test: the allow-list
+    assert ops.radix_sort_prepare() == 1                  # the self-test agrees
     keys = ops.gen_uniform_u32(1 << 20, 3, 0, 2**32 - 1)
     ops.radix_sort_(keys, signed=False, radix_bits=8)
     assert _capi.lib().dbhip_radix_sort_rank_mode() == 1
@@ -133,3 +133,32 @@ def test_rank_by_lds_atomics_is_self_checked_and_both_rankings_agree():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300,
                            env={**os.environ, "DBHIP_RS_RANK": mode}, cwd=os.path.dirname(os.path.dirname(__file__)))
         assert r.returncode == 0 and want in r.stdout, (mode, r.stdout, r.stderr)
+
+
+def test_unstable_ranking_raises_the_rank_order_status():
+    """Every tile of every pass checks the invariant the stable ranking exists for (a tile re-ordered by the pass's digit
+    is sorted by its lower digits).  DBHIP_RS_INJECT_UNSTABLE=1 swaps one pair of neighbours inside a digit run of the
+    first tile, after the ranking and before the write-out — what an unstable rank would produce: the status word must
+    carry DBHIP_DEV_RANK_ORDER (and the result really is mis-sorted), in both rank modes and both digit widths; the same
+    program without the injection is clean."""
+    import os, subprocess, sys
+    prog = (
+        "import numpy as np, torch\n"
+        "from dwarf_bench_amd import ops\n"
+        "bad = 0\n"
+        "for n in (100003, (1 << 21) + 5):\n"
+        "    for bits in (8, 4):\n"
+        "        k = ops.gen_uniform_u32(n, 11, 0, 2**32 - 1); h = np.sort(k.cpu().numpy().view(np.uint32))\n"
+        "        plan = ops.RadixSort(n, bits); plan.launch(k); torch.cuda.synchronize()\n"
+        "        st = ops.workspace_status(plan.ws)\n"
+        "        same = bool(np.array_equal(k.cpu().numpy().view(np.uint32), h))\n"
+        "        assert (st == 0) == same, (n, bits, st, same)\n"
+        "        assert st in (0, ops.DEV_RANK_ORDER), st\n"
+        "        bad += st != 0\n"
+        "print('flagged', bad)\n")
+    for mode in ("atomic", "ballot"):
+        for inject, want in (("1", "flagged 4"), ("0", "flagged 0")):
+            r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300,
+                               env={**os.environ, "DBHIP_RS_RANK": mode, "DBHIP_RS_INJECT_UNSTABLE": inject},
+                               cwd=os.path.dirname(os.path.dirname(__file__)))
+            assert r.returncode == 0 and want in r.stdout, (mode, inject, r.stdout, r.stderr)

@@ -1,0 +1,272 @@
+"""development aid: `python tools/ab.py <dwarf> [log2 size]` — HIP-event timings of one dwarf through the C ABI, one
+line per run, for A/B comparisons of library builds (DBHIP_LIB=<path to a libdbhip_*.so built by tools/build_variant.sh>
+selects the build; the line starts with its tag).  Every mode also checks its result against torch, so a faster
+variant that computes something else shows up as WRONG.  This is how the per-kernel figures in DESIGN.md were taken;
+the contract numbers come from bench.py.
+
+  scan            two-launch vs dense copy_if at 2^28 rows over a selectivity sweep (median of 9)
+  sort [lg]       2^lg-key sort, 8- and 4-bit digits (drop-max-mean of 9, refresh copy subtracted); default lg 24
+  sort-only       three 2^24 sorts and nothing else (counter collection; SORT_BITS=4|8)
+  groupby         2^26 rows at 2^16 / 2^15 / 2^10 / 64 groups (drop-max-mean of 9)
+  join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
+  partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
+  reduce          2^28-row reduce (median of 15; DBHIP_RED_WGS)
+  xscan [lg]      exclusive scan of 2^lg uint32, aligned (one launch) and offset by one element (three launches)
+  graph           direct launches vs hipGraph replay of sort and join at 2^14..2^20 rows (host wall clock)
+  launch-join [lg] / launch-sort [lg] / launch-all
+                  a few untimed calls and nothing else: the program to put behind `rocprofv3 --kernel-trace --stats` or
+                  `--pmc` (tools/pmc_kernel_counters.sh); tools/prof_show.py prints the tables
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from dwarf_bench_amd import ops  # noqa: E402
+
+TAG = os.environ.get("DBHIP_LIB", "default").split("libdbhip_")[-1]
+
+
+def times(fn, k, warm=2):
+    """device time of k calls, us each (events on torch's current stream = the launch stream), sorted"""
+    for _ in range(warm):
+        fn()
+    out = []
+    for _ in range(k):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) * 1e3)
+    return sorted(out)
+
+
+def dropmax(ts):
+    return sum(ts[:-1]) / (len(ts) - 1)
+
+
+def median(ts):
+    return ts[len(ts) // 2]
+
+
+def u64(t):
+    return t.to(torch.int64) & 0xFFFFFFFF
+
+
+def scan(_):
+    n = 1 << 28
+    src = ops.gen_uniform_u32(n, 42, 1, 10000)
+    plan = ops.CopyIfLt(n)
+    for filt in (5, 101, 1001, 2501, 5001, 7501, 10001):
+        t0 = median(times(lambda: plan.launch(src, filt, dense=False), 9))
+        m = plan.result().numel()
+        t1 = median(times(lambda: plan.launch(src, filt, dense=True), 9))
+        m1 = plan.result().numel()
+        byts = 4 * n + 4 * m
+        print(f"{TAG:16s} s={m / n:6.4f}: two-launch {t0:7.1f} us ({byts / t0 / 8e6 * 100:4.1f} %)   dense {t1:7.1f} us "
+              f"({byts / t1 / 8e6 * 100:4.1f} %)  {'same count' if m == m1 == int((src < filt).sum()) else 'COUNT DIFFERS'}", flush=True)
+
+
+def sort(lg):
+    n = 1 << (lg or 24)
+    keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    keys = keys0.clone()
+    ref = torch.sort(u64(keys0)).values
+    res = []
+    for bits in (8, 4):
+        plan = ops.RadixSort(n, bits)
+
+        def run():
+            keys.copy_(keys0)
+            plan.launch(keys)
+
+        t = dropmax(times(run, 9)) - dropmax(times(lambda: keys.copy_(keys0), 9))
+        run()
+        ok = bool(torch.equal(u64(keys), ref)) and ops.workspace_status(plan.ws) == 0
+        res.append(f"{bits}-bit {t:7.1f} us {'ok' if ok else 'WRONG'}")
+    print(f"{TAG:24s} 2^{lg or 24}: " + "   ".join(res), flush=True)
+
+
+def sort_only(_):
+    n = 1 << 24
+    keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    keys = keys0.clone()
+    plan = ops.RadixSort(n, int(os.environ.get("SORT_BITS", "8")))
+    for _i in range(3):
+        keys.copy_(keys0)
+        plan.launch(keys)
+    torch.cuda.synchronize()
+    print("ok")
+
+
+def groupby(_):
+    n = 1 << 26
+    res = []
+    for groups in (1 << 16, 1 << 15, 1 << 10, 64):
+        keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+        vals = ops.gen_uniform_u32(n, 43, 1, 10000)
+        plan = ops.GroupBySum(n, groups)
+        t = dropmax(times(lambda: plan.launch(keys, vals), 9))
+        ref = torch.zeros(groups, dtype=torch.int64, device="cuda").index_add_(0, keys.to(torch.int64), vals.to(torch.int64))
+        ok = bool(torch.equal(u64(plan.result()), ref & 0xFFFFFFFF))
+        res.append(f"G={groups}: {t:6.1f} us {'ok' if ok else 'WRONG'}")
+    print(f"{TAG:16s} " + "  ".join(res), flush=True)
+
+
+def join(lg):
+    lg = lg or 26
+    n = 1 << lg
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    plan = ops.HashJoin(n, n)
+    plan.build(build)
+    plan.probe(probe)
+    b = dropmax(times(lambda: plan.build(build), 7, warm=0))
+    p = dropmax(times(lambda: plan.probe(probe), 7, warm=0))
+    plan.result()
+    total = int(plan.cnt.to(torch.int64).sum())
+    del plan
+    rj = ops.RadixJoin(n, n)
+
+    def radix():
+        rj.partition_build(build)
+        rj.partition_probe(probe)
+        rj.match()
+
+    r = dropmax(times(radix, 7, warm=1))
+    pb = dropmax(times(lambda: rj.partition_build(build), 7, warm=0))
+    m = dropmax(times(rj.match, 7, warm=0))
+    rj.result()
+    ok = int(rj.cnt.to(torch.int64).sum()) == total
+    print(f"{TAG:20s} 2^{lg}: build {b:8.1f} probe {p:8.1f} total {b + p:8.1f} us | radix join {r:8.1f} us "
+          f"(partition one side {pb:7.1f}, match {m:7.1f}) matches {'equal' if ok else 'DIFFER'}", flush=True)
+
+
+def partition(_):
+    n = 1 << 27
+    keys = ops.gen_uniform_u32(n, 42, 0, (1 << 30) - 1)
+    for parts in (2, 4, 8, 16, 64, 256):
+        t = median(times(lambda: ops.partition_by_hash(keys, 0, parts), 5, warm=1))
+        print(f"{TAG:12s} 2^27 rows -> {parts:4d} buckets: {t:8.1f} us (incl. output allocation)", flush=True)
+
+
+def reduce(_):
+    n = 1 << 28
+    src = ops.gen_uniform_u32(n, 42, 1, 10000)
+    want = int(src.sum(dtype=torch.int64)) & 0xFFFFFFFF
+    t = median(times(lambda: ops.reduce_sum(src), 15, warm=3))
+    got = int(ops.reduce_sum(src)) & 0xFFFFFFFF
+    print(f"{TAG:12s} wgs={os.environ.get('DBHIP_RED_WGS', '-')}: {t:7.1f} us ({4 * n / t / 8e6 * 100:4.1f} %) "
+          f"{'ok' if got == want else 'WRONG'}", flush=True)
+
+
+def xscan(lg):
+    lg = lg or 28
+    n = 1 << lg
+    base = ops.gen_uniform_u32(n + 4, 42, 0, 1000)
+    outb = torch.empty(n + 4, dtype=torch.int32, device="cuda")
+    for off in (0, 1):
+        src, out = base[off: off + n], outb[off: off + n]
+        plan = ops.ExclusiveScan(n)
+        t = median(times(lambda: plan.launch(src, out=out), 9))
+        plan.result()
+        m = min(n - 1, 1 << 20)
+        ref = torch.cumsum(src[:m].to(torch.int64), 0)
+        ok = bool(torch.equal(u64(out[1:m + 1]), ref & 0xFFFFFFFF)) and int(out[0]) == 0
+        print(f"{TAG:12s} 2^{lg} offset {off}: {t:8.1f} us  ({8 * n / t / 8e6 * 100:4.1f} % of 8 TB/s on 8n bytes)  "
+              f"{'ok' if ok else 'WRONG'}", flush=True)
+
+
+def graph(_):
+    import time
+
+    def wall(fn, iters=200):
+        for _i in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _i in range(iters):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e6
+
+    def captured(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    for lg in (14, 16, 18, 20):
+        n = 1 << lg
+        keys = ops.gen_uniform_u32(n, 1, 0, 2**32 - 1)
+        plan = ops.RadixSort(n, 8)
+        direct = wall(lambda: plan.launch(keys))
+        replay = wall(captured(lambda: plan.launch(keys)).replay)
+        b, p = ops.gen_uniform_u32(n, 2, 0, n - 1), ops.gen_uniform_u32(n, 3, 0, n - 1)
+        j = ops.HashJoin(n, n)
+
+        def both():
+            j.build(b)
+            j.probe(p)
+
+        jd = wall(both)
+        jg = wall(captured(both).replay)
+        print(f"n=2^{lg}: sort direct {direct:.1f} us  graph {replay:.1f} us | join direct {jd:.1f} us  graph {jg:.1f} us", flush=True)
+
+
+def launch_join(lg):
+    n = 1 << (lg or 26)
+    build, probe = ops.gen_uniform_u32(n, 42, 0, n - 1), ops.gen_uniform_u32(n, 43, 0, n - 1)
+    plan = ops.HashJoin(n, n)
+    for _i in range(5):
+        plan.build(build)
+        plan.probe(probe)
+    torch.cuda.synchronize()
+    plan.result()
+    print("ok")
+
+
+def launch_sort(lg):
+    n = 1 << (lg or 24)
+    keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    for bits in (8, 4):
+        plan = ops.RadixSort(n, bits)
+        for _i in range(5):
+            k = keys0.clone()
+            plan.launch(k)
+    torch.cuda.synchronize()
+    print("ok")
+
+
+def launch_all(_):
+    """a few calls of every BASELINE configuration (SQ counters per kernel)"""
+    n = 1 << 28
+    src = ops.gen_uniform_u32(n, 42, 1, 10000)
+    sc = ops.CopyIfLt(n)
+    for filt in (5, 5, 5001, 5001):
+        sc.launch(src, filt, dense=filt > 1000)
+    del src, sc
+    launch_sort(24)
+    n = 1 << 26
+    keys, vals = ops.gen_uniform_u32(n, 42, 0, 65535), ops.gen_uniform_u32(n, 43, 1, 10000)
+    gb = ops.GroupBySum(n, 1 << 16)
+    for _i in range(3):
+        gb.launch(keys, vals)
+    torch.cuda.synchronize()
+    print("ok")
+
+
+MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "join": join, "partition": partition,
+         "reduce": reduce, "xscan": xscan}
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] not in MODES:
+        raise SystemExit(__doc__)
+    MODES[sys.argv[1]](int(sys.argv[2]) if len(sys.argv) > 2 else None)

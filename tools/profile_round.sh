@@ -4,9 +4,9 @@
 #      configuration or the small result check)
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own passes (HBM traffic per launch; MI355X_MICROARCH.md)
 # Raw output goes to gpurun_out/prof_<tag>/; tools/profile_summary.py condenses it into profiles/.
-#   tools/profile_r02.sh <tag> <git head the numbers belong to>
+#   tools/profile_round.sh <tag> <git head the numbers belong to>
 set -euo pipefail
-tag="${1:-r02}"; head="${2:-unknown}"
+tag="${1:-r03}"; head="${2:-unknown}"
 repo="$(pwd)"
 out="$repo/gpurun_out/prof_$tag"
 mkdir -p "$out"
@@ -20,3 +20,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o pmc -- pyt
 echo "[profile] WRITE_SIZE done"
 cd "$repo"
 python3 tools/profile_summary.py "$out" "$tag" "$head"
+# the self-measured peaks bench.py divides by (RANDOM_GATHER_PEAK_G, LDS_ATOMIC_PEAK_G, the nt-read rate): raw output of
+# the two micro-benchmarks, with the command and the git head, kept as profiles/<tag>_ubench.txt
+for b in ubench ubench_lds; do
+  if [ ! -x "tools/$b" ] || [ "tools/$b.hip" -nt "tools/$b" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "tools/$b.hip" -o "tools/$b"; fi
+done
+{ echo "# git head $head, tag $tag; commands: tools/ubench ; tools/ubench_lds (sources tools/ubench.hip, tools/ubench_lds.hip,"
+  echo "# built with hipcc --offload-arch=gfx950 -O3), run on the GPU box by tools/profile_round.sh"
+  echo "## tools/ubench"; ./tools/ubench; echo "## tools/ubench_lds"; ./tools/ubench_lds; } > "profiles/${tag}_ubench.txt" 2>&1
+cp "profiles/${tag}_ubench.txt" "$out/"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the raw rocprofv3 output of tools/profile_r02.sh into the small files kept under profiles/:
+"""Condense the raw rocprofv3 output of tools/profile_round.sh into the small files kept under profiles/:
 
   profiles/<tag>_bench_kernel_stats.csv   the --kernel-trace --stats table of `bench.py --no-sweep --no-cpu` (verbatim)
   profiles/<tag>_headline.json            the same trace split per BASELINE configuration: for every kernel of a
@@ -160,9 +160,9 @@ def main():
                          "WRITE_SIZE_KiB_mean": sum(w) / len(w) if w else None, "WRITE_SIZE_KiB_max": max(w) if w else None}
     (prof / f"{tag}_pmc.json").write_text(json.dumps({
         "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep ; same with "
-                   "--pmc WRITE_SIZE (separate passes, tools/profile_r02.sh)", "git_head": git_head, "kernels": per_kernel}, indent=1))
+                   "--pmc WRITE_SIZE (separate passes, tools/profile_round.sh)", "git_head": git_head, "kernels": per_kernel}, indent=1))
 
-    traffic = {"_source": {"tool": "tools/profile_r02.sh -> tools/profile_summary.py", "round_tag": tag, "git_head": git_head,
+    traffic = {"_source": {"tool": "tools/profile_round.sh -> tools/profile_summary.py", "round_tag": tag, "git_head": git_head,
                            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 10 --warmup 2 "
                                       "--no-cpu --no-pjoin --no-sweep (one counter per pass)"},
                "_comment": "HBM bytes per call from rocprofv3 --pmc passes (profiles/%s_pmc.json); counters are KiB; "
