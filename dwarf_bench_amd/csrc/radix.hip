@@ -59,6 +59,9 @@ constexpr int kRsKpt = DBHIP_RS_KPT;             // keys per lane per tile
 constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
 constexpr int kRsMaxRadix = 256;
+#ifndef DBHIP_RS_CHECK_MOD
+#define DBHIP_RS_CHECK_MOD 5  // the order check looks at the 512-key bands k = 0, 5, 10, 15 of a tile (experiments: 1 = all, 99 = first)
+#endif
 #ifndef DBHIP_RS_CHUNKS
 #define DBHIP_RS_CHUNKS 2048
 #endif
@@ -68,13 +71,18 @@ constexpr size_t kRs4MaxChunks = kRsTargetChunks / 2;  // 4-bit: at most this ma
 static_assert(kRs4MaxChunks <= 1024, "rs_scan4 is one workgroup with one thread per chunk");
 
 struct RsHeader {
-  unsigned status;
-  // which key bits take both values somewhere in the input = or_bits & nor_bits (OR of the keys, OR of their
-  // complements; both start at 0 with the cleared header).  A pass is skipped iff none of its digit's bits varies.
-  unsigned or_bits, nor_bits;
-  unsigned pad[61];
+  unsigned status, pad0;
+  // low word: OR of the keys, high word: OR of their complements (both start at 0 with the cleared header).  A key bit
+  // takes both values somewhere in the input iff it is set in both words; a pass is skipped iff none of its digit's
+  // bits does.
+  unsigned long long or_nor;
+  unsigned pad[60];
 };
 static_assert(sizeof(RsHeader) == kWsHeader, "workspace header size");
+__device__ __forceinline__ unsigned rs_varying(const RsHeader *hdr) {
+  const unsigned long long w = hdr->or_nor;
+  return static_cast<unsigned>(w) & static_cast<unsigned>(w >> 32);
+}
 
 // what every kernel derives from the header word for ITS pass
 template <int BITS>
@@ -150,38 +158,61 @@ __device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popc
 template <int BITS>
 constexpr int rs_hist_cpw() { return BITS == 8 ? 4 : 1; }
 
-// Byte histogram of one chunk into s_bins[256] (LDS, cleared by the caller): one ds_add per key on the byte that holds
-// the pass's digit.  A byte that is the same in the whole wave (upper bytes of small keys: the reference's [1,10000]
-// data) would serialise 64 same-address ds_add: one lane adds the lot instead.
-__device__ __forceinline__ void rs_count_chunk_bytes(const unsigned *__restrict__ src, size_t lo, size_t hi, int byte_shift,
-                                                     unsigned xor_mask, unsigned *s_bins, unsigned &my_or, unsigned &my_nor) {
-  const size_t n4 = (hi - lo) / 4;  // chunk starts are multiples of the tile size: 16-byte loads are aligned
-  const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + lo);
-  // (issuing a tile's four 16-byte loads per lane before the first LDS atomic, non-temporal, measured no faster)
-  for (size_t i = threadIdx.x; i < n4; i += kRsThreads) {
-    const u32x4 v = k4[i];
-    my_or |= v.x | v.y | v.z | v.w;
-    my_nor |= ~(v.x & v.y & v.z & v.w);
-    const unsigned b0 = ((v.x ^ xor_mask) >> byte_shift) & 255u, b1 = ((v.y ^ xor_mask) >> byte_shift) & 255u,
-                   b2 = ((v.z ^ xor_mask) >> byte_shift) & 255u, b3 = ((v.w ^ xor_mask) >> byte_shift) & 255u;
-    const unsigned first = __builtin_amdgcn_readfirstlane(b0);
-    const bool same = b0 == first && b1 == first && b2 == first && b3 == first;
-    const unsigned long long active = __ballot(true);
-    if (__ballot(same) == active) {
-      if (threadIdx.x % kWave == static_cast<unsigned>(__builtin_ctzll(active)))
-        atomicAdd(&s_bins[first], 4u * static_cast<unsigned>(__builtin_popcountll(active)));
-    } else {
-      atomicAdd(&s_bins[b0], 1u);
-      atomicAdd(&s_bins[b1], 1u);
-      atomicAdd(&s_bins[b2], 1u);
-      atomicAdd(&s_bins[b3], 1u);
-    }
+// Byte histogram of the tiles [t0, t1) of the input — consecutive chunks of `tiles_per_chunk` tiles each, the first one
+// counted into s_bins[0], the next into s_bins[1], ... (LDS, cleared by the caller): one ds_add per key on the byte that
+// holds the pass's digit.  The next tile's four 16-byte loads per lane are in flight while the current tile is counted
+// (one load in flight per lane made the up-front read latency-bound: 28 us for 64 MiB that come from HBM, against 13 us
+// for the per-pass histograms whose input lies in the Infinity Cache).  A byte that is the same in the whole wave (upper
+// bytes of small keys: the reference's [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot.
+__device__ __forceinline__ void rs_count4(const u32x4 v, int byte_shift, unsigned xor_mask, unsigned *bins, unsigned &my_or,
+                                          unsigned &my_nor) {
+  my_or |= v.x | v.y | v.z | v.w;
+  my_nor |= ~(v.x & v.y & v.z & v.w);
+  const unsigned b0 = ((v.x ^ xor_mask) >> byte_shift) & 255u, b1 = ((v.y ^ xor_mask) >> byte_shift) & 255u,
+                 b2 = ((v.z ^ xor_mask) >> byte_shift) & 255u, b3 = ((v.w ^ xor_mask) >> byte_shift) & 255u;
+  const unsigned first = __builtin_amdgcn_readfirstlane(b0);
+  const bool same = b0 == first && b1 == first && b2 == first && b3 == first;
+  if (__ballot(same) == __ballot(true)) {
+    if (lane_id() == 0) atomicAdd(&bins[first], 4u * kWave);  // (only reached with all 64 lanes active: full tiles)
+  } else {
+    atomicAdd(&bins[b0], 1u);
+    atomicAdd(&bins[b1], 1u);
+    atomicAdd(&bins[b2], 1u);
+    atomicAdd(&bins[b3], 1u);
   }
-  for (size_t i = lo + n4 * 4 + threadIdx.x; i < hi; i += kRsThreads) {  // ragged end of the last chunk
-    const unsigned k = src[i];
-    my_or |= k;
-    my_nor |= ~k;
-    atomicAdd(&s_bins[((k ^ xor_mask) >> byte_shift) & 255u], 1u);
+}
+__device__ __forceinline__ void rs_count_tiles(const unsigned *__restrict__ src, size_t n, size_t t0, size_t t1,
+                                               size_t tiles_per_chunk, int byte_shift, unsigned xor_mask,
+                                               unsigned (*s_bins)[256], unsigned &my_or, unsigned &my_nor) {
+  constexpr int kVec = kRsTile / 4 / kRsThreads;  // 16-byte loads per lane and tile
+  const size_t full_end = n / kRsTile < t1 ? n / kRsTile : t1;  // tiles below this index are complete
+  u32x4 cur[kVec], nxt[kVec];
+  if (t0 < full_end) {
+    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + t0 * kRsTile);  // tile starts are 32 KiB multiples: aligned
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) cur[j] = k4[threadIdx.x + j * kRsThreads];
+  }
+#pragma unroll 1
+  for (size_t t = t0; t < full_end; ++t) {
+    if (t + 1 < full_end) {
+      const u32x4 *k4 = reinterpret_cast<const u32x4 *>(src + (t + 1) * kRsTile);
+#pragma unroll
+      for (int j = 0; j < kVec; ++j) nxt[j] = k4[threadIdx.x + j * kRsThreads];
+    }
+    unsigned *bins = s_bins[(t - t0) / tiles_per_chunk];
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) rs_count4(cur[j], byte_shift, xor_mask, bins, my_or, my_nor);
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) cur[j] = nxt[j];
+  }
+  if (full_end < t1) {  // the input's ragged last tile
+    unsigned *bins = s_bins[(full_end - t0) / tiles_per_chunk];
+    for (size_t i = full_end * kRsTile + threadIdx.x; i < n; i += kRsThreads) {
+      const unsigned k = src[i];
+      my_or |= k;
+      my_nor |= ~k;
+      atomicAdd(&bins[((k ^ xor_mask) >> byte_shift) & 255u], 1u);
+    }
   }
 }
 
@@ -219,34 +250,43 @@ template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_upfront_kernel(const unsigned *__restrict__ keys, size_t n, unsigned xor_mask,
                                                                 RsHeader *hdr, unsigned *__restrict__ counts0,
                                                                 size_t tiles_per_chunk, size_t num_chunks) {
+  // The two OR words reach the header through ONE 64-bit atomic per workgroup, issued after the workgroup's FIRST group of
+  // chunks (for most inputs every varying bit has shown up by then) so that it drains while the workgroup streams on, and
+  // once more at the end only if later keys added a bit: same-address global atomics are served one per ~11 ns, and two
+  // per workgroup at the end of 1024 workgroups made this kernel 34 us instead of 14.
   constexpr int kCpw = rs_hist_cpw<BITS>();
   __shared__ unsigned s_bins[kCpw][256];
   __shared__ unsigned s_or, s_nor;
   if (threadIdx.x == 0) s_or = s_nor = 0;
   unsigned my_or = 0, my_nor = 0;
-  const size_t chunk_keys = tiles_per_chunk * kRsTile;
+  unsigned long long published = 0;  // thread 0: what this workgroup has already added to the header
+  const size_t total_tiles = (n + kRsTile - 1) / kRsTile;
   const size_t groups = (num_chunks + kCpw - 1) / kCpw;
   for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
+    const bool first = group == blockIdx.x;
     for (int i = threadIdx.x; i < kCpw * 256; i += kRsThreads) (&s_bins[0][0])[i] = 0;
     __syncthreads();
-#pragma unroll 1
-    for (int cc = 0; cc < kCpw; ++cc) {
-      const size_t chunk = group * kCpw + cc;
-      if (chunk >= num_chunks) break;
-      const size_t lo = chunk * chunk_keys;
-      const size_t hi = lo + chunk_keys < n ? lo + chunk_keys : n;
-      rs_count_chunk_bytes(keys, lo, hi, 0, xor_mask, s_bins[cc], my_or, my_nor);
+    const size_t t0 = group * kCpw * tiles_per_chunk;
+    const size_t t1 = t0 + kCpw * tiles_per_chunk < total_tiles ? t0 + kCpw * tiles_per_chunk : total_tiles;
+    rs_count_tiles(keys, n, t0, t1, tiles_per_chunk, 0, xor_mask, s_bins, my_or, my_nor);
+    if (first) {
+      if (my_or & ~s_or) atomicOr(&s_or, my_or);
+      if (my_nor & ~s_nor) atomicOr(&s_nor, my_nor);
     }
     __syncthreads();
     rs_store_chunk_counts<BITS>(s_bins, counts0, group * kCpw, num_chunks, 0);
+    if (first && threadIdx.x == 0) {
+      published = static_cast<unsigned long long>(s_or) | (static_cast<unsigned long long>(s_nor) << 32);
+      if (published) atomicOr(&hdr->or_nor, published);
+    }
     __syncthreads();
   }
-  if (my_or) atomicOr(&s_or, my_or);
-  if (my_nor) atomicOr(&s_nor, my_nor);
+  if (my_or & ~s_or) atomicOr(&s_or, my_or);
+  if (my_nor & ~s_nor) atomicOr(&s_nor, my_nor);
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (s_or) atomicOr(&hdr->or_bits, s_or);
-    if (s_nor) atomicOr(&hdr->nor_bits, s_nor);
+    const unsigned long long all = static_cast<unsigned long long>(s_or) | (static_cast<unsigned long long>(s_nor) << 32);
+    if (all & ~published) atomicOr(&hdr->or_nor, all);
   }
 }
 
@@ -260,7 +300,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
                                                                    size_t tiles_per_chunk, size_t num_chunks) {
   constexpr int kCpw = rs_hist_cpw<BITS>();
   __shared__ unsigned s_bins[kCpw][256];
-  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+  const unsigned varying = rs_varying(hdr);
   if (FIRST) {
     if (rs_varies<BITS>(varying, 0)) return;  // the common case: rs_upfront counted the right digit
     pass = rs_next_pass<BITS>(varying, 0);
@@ -270,21 +310,19 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
   }
   const unsigned *__restrict__ src = rs_parity<BITS>(varying, pass) ? tmp : keys;
   const int byte_shift = (pass * BITS) & ~7;
-  const size_t chunk0 = static_cast<size_t>(blockIdx.x) * kCpw;
-  for (int i = threadIdx.x; i < kCpw * 256; i += kRsThreads) (&s_bins[0][0])[i] = 0;
-  __syncthreads();
+  const size_t total_tiles = (n + kRsTile - 1) / kRsTile;
+  const size_t groups = (num_chunks + kCpw - 1) / kCpw;
   unsigned unused_or = 0, unused_nor = 0;
-#pragma unroll 1
-  for (int c = 0; c < kCpw; ++c) {
-    const size_t chunk = chunk0 + c;
-    if (chunk >= num_chunks) break;
-    const size_t lo = chunk * tiles_per_chunk * kRsTile;
-    size_t hi = lo + tiles_per_chunk * kRsTile;
-    hi = hi < n ? hi : n;
-    rs_count_chunk_bytes(src, lo, hi, byte_shift, xor_mask, s_bins[c], unused_or, unused_nor);
+  for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
+    for (int i = threadIdx.x; i < kCpw * 256; i += kRsThreads) (&s_bins[0][0])[i] = 0;
+    __syncthreads();
+    const size_t t0 = group * kCpw * tiles_per_chunk;
+    const size_t t1 = t0 + kCpw * tiles_per_chunk < total_tiles ? t0 + kCpw * tiles_per_chunk : total_tiles;
+    rs_count_tiles(src, n, t0, t1, tiles_per_chunk, byte_shift, xor_mask, s_bins, unused_or, unused_nor);
+    __syncthreads();
+    rs_store_chunk_counts<BITS>(s_bins, counts, group * kCpw, num_chunks, BITS == 4 ? (pass & 1) : 0);
+    __syncthreads();
   }
-  __syncthreads();
-  rs_store_chunk_counts<BITS>(s_bins, counts, chunk0, num_chunks, BITS == 4 ? (pass & 1) : 0);
 }
 
 // ---- 8-bit, per pass: counts[d][*] -> start of digit d in every chunk relative to the digit's base; row total ----------
@@ -296,7 +334,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   constexpr unsigned kMaxPer = 8;
   static_assert(kRsTargetChunks <= static_cast<size_t>(kMaxPer) * kRsThreads, "chunks per scan workgroup");
   __shared__ unsigned s_wsum[kRsWaves];
-  if (!rs_varies<8>(hdr->or_bits & hdr->nor_bits, pass)) return;
+  if (!rs_varies<8>(rs_varying(hdr), pass)) return;
   const unsigned d = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned *row = counts + static_cast<size_t>(d) * num_chunks;
   const unsigned per = static_cast<unsigned>((num_chunks + kRsThreads - 1) / kRsThreads);
@@ -329,9 +367,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
 __global__ __launch_bounds__(1024) void rs_scan4_kernel(int pass, const RsHeader *hdr, unsigned *cnt2, unsigned *__restrict__ off,
                                                         size_t num_chunks) {
   constexpr int kW = 1024 / kWave;
-  __shared__ unsigned s_w[kW][16];  // per-wave digit sums, then exclusive over the waves
-  __shared__ unsigned s_base[16];
-  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+  __shared__ unsigned s_w[kW][17];  // per-wave digit sums, then exclusive over the waves
+  __shared__ unsigned s_tot[16], s_base[16];
+  static_assert(kW == 16, "the cross-wave scan below is one 16-lane DPP row per digit");
+  // (requesting the rows of BOTH matrices together with the header word that says which one is current, to save a
+  //  dependent round trip, was measured: 7.8 -> 9.0 us.  About 4.5 us of this kernel's time is the write-back of what
+  //  the scatter before it left dirty in the L2s: a kernel that only reads the header and returns takes 4.8 us here.)
+  const unsigned varying = rs_varying(hdr);
   if (!rs_varies<4>(varying, pass)) return;
   const unsigned par = rs_parity<4>(varying, pass);
   const u32x4 *__restrict__ cur = reinterpret_cast<const u32x4 *>(cnt2 + static_cast<size_t>(par) * num_chunks * 16);
@@ -351,14 +393,20 @@ __global__ __launch_bounds__(1024) void rs_scan4_kernel(int pass, const RsHeader
     if (lane == kWave - 1) s_w[wave][d] = incl[d];
   }
   __syncthreads();
-  if (tid < 16) {  // digit tid: exclusive over the waves, digit total
-    unsigned run = 0;
-    for (int w = 0; w < kW; ++w) {
-      const unsigned t = s_w[w][tid];
-      s_w[w][tid] = run;
-      run += t;
-    }
-    // exclusive scan of the 16 totals inside the first 16 lanes of wave 0 (row_shr stays inside a 16-lane row)
+  if (tid < 256) {  // lane = (digit, wave) with the wave in the low four bits: one 16-lane DPP row per digit
+    const unsigned d = tid >> 4, w = tid & 15u;
+    const unsigned t = s_w[w][d];
+    unsigned x = t;
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1 (stays inside the row)
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);
+    s_w[w][d] = x - t;
+    if (w == 15u) s_tot[d] = x;
+  }
+  __syncthreads();
+  if (tid < 16) {  // exclusive scan of the 16 digit totals
+    const unsigned run = s_tot[tid];
     unsigned x = run;
     x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);
     x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);
@@ -452,22 +500,25 @@ struct RsLds {
   unsigned (*cnt)[1 << BITS];  // per-wave digit counts, then wave-exclusive offsets
   unsigned *dexcl;             // tile-local exclusive offset of each digit
   unsigned *goff;              // global offset of a digit minus its local offset
-  unsigned *wsum;
+  unsigned *wsum, *wsum2;
   unsigned *keys;
   unsigned *bnd;               // 4-bit: first output position of digit d that belongs to the SECOND destination chunk
-  unsigned *h2;                // 4-bit: [2][16][16] next-digit counts per (destination chunk, digit)
+  unsigned *thr;               // 4-bit, per tile: first LDS slot of digit d whose key goes to the second chunk
+  unsigned *h2;                // 4-bit: [16][16][2] next-digit counts per (digit, next digit, first / second destination chunk)
 };
 
 // One tile of the scatter: stable rank inside each wave, digit offsets across waves, re-order through LDS, write out
 // in digit order.  FULL = the tile holds kRsTile keys: no per-key bounds checks (the kernel is VALU-bound — about 100
 // vector instructions per 64 keys with ballots, 80 % of the issue slots at 2^24 keys by the SQ counters).
 // shift2 >= 0 (4-bit only): count the digit at shift2 of every key against its destination chunk (see the file header).
+// base_from (8-bit only, the workgroup's first tile): `running` is still relative to the digit's base; the base = the
+// exclusive scan of the digits' totals (total_d) rides on the tile's own scan and barrier.
 // Returns nonzero if the tile, re-ordered by its digit, was not sorted by its low (shift + BITS) bits.
 template <int BITS, bool FULL, bool ARANK>
 __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__ src, unsigned *__restrict__ dst,
                                                     size_t tile_base, unsigned valid_in_tile, int shift, int shift2,
-                                                    unsigned xor_mask, unsigned low_mask, bool inject, unsigned &running,
-                                                    const RsLds<BITS> &L) {
+                                                    unsigned xor_mask, unsigned low_mask, bool inject, bool base_from,
+                                                    unsigned total_d, unsigned &running, const RsLds<BITS> &L) {
   constexpr int kRadix = 1 << BITS;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const unsigned wave_first = wave * kRsWaveKeys + lane;
@@ -514,23 +565,46 @@ __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__
     }
   }
   const unsigned incl = wave_inclusive_scan(tile_count);
-  if (lane == kWave - 1) L.wsum[wave] = incl;
+  unsigned incl_t = 0;
+  if (BITS == 8 && base_from) incl_t = wave_inclusive_scan(total_d);
+  if (lane == kWave - 1) {
+    L.wsum[wave] = incl;
+    if (BITS == 8 && base_from) L.wsum2[wave] = incl_t;
+  }
   __syncthreads();
   unsigned dexcl = incl - tile_count;
   for (unsigned w = 0; w < wave; ++w) dexcl += L.wsum[w];
+  if (BITS == 8 && base_from) {
+    unsigned base = incl_t - total_d;
+    for (unsigned w = 0; w < wave; ++w) base += L.wsum2[w];
+    running += base;
+  }
   if (tid < kRadix) {
     L.dexcl[tid] = dexcl;
     L.goff[tid] = running - dexcl;
+    if (BITS == 4) {  // keys of this digit with a run index >= bnd - running go to the second destination chunk
+      const unsigned b = L.bnd[tid];
+      const unsigned room = b > running ? b - running : 0u;
+      L.thr[tid] = dexcl + (room < tile_count ? room : tile_count);
+    }
     running += tile_count;
   }
   __syncthreads();
 
-  // ---- re-order the tile by digit in LDS
+  // ---- re-order the tile by digit in LDS; 4-bit: count the key's next digit against its destination chunk here, where
+  // the lanes of a wave hold keys of all digits (in the write-out loop a wave holds ONE digit's run: 64 lanes on 16
+  // counters, 4-way same-address and bank conflicts on every instruction: the scatter took 40 us instead of 27)
 #pragma unroll
   for (int j = 0; j < kRsKpt; ++j) {
     if (FULL || wave_first + j * kWave < valid_in_tile) {
-      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-      L.keys[L.dexcl[d] + L.cnt[wave][d] + rank[j]] = key[j];
+      const unsigned kx = key[j] ^ xor_mask;
+      const unsigned d = (kx >> shift) & (kRadix - 1);
+      const unsigned slot = L.dexcl[d] + L.cnt[wave][d] + rank[j];
+      L.keys[slot] = key[j];
+      if (BITS == 4 && shift2 >= 0) {
+        const unsigned d2 = (kx >> shift2) & (kRadix - 1);
+        atomicAdd(&L.h2[((d << 4 | d2) << 1) + (slot >= L.thr[d] ? 1u : 0u)], 1u);
+      }
     }
   }
   __syncthreads();
@@ -557,16 +631,17 @@ __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__
       const unsigned kk = L.keys[p];
       const unsigned kx = kk ^ xor_mask;
       // the tile as it now lies in LDS must be sorted by its low (shift + BITS) bits (stable ranking, here and in
-      // every earlier pass): my left neighbour's may not exceed mine
-      const unsigned left = L.keys[p ? p - 1 : 0] ^ xor_mask;
-      bad |= (left & low_mask) > (kx & low_mask) ? 1u : 0u;
-      const unsigned d = (kx >> shift) & (kRadix - 1);
-      const unsigned pos = L.goff[d] + p;
-      dst[pos] = kk;
-      if (BITS == 4 && shift2 >= 0) {
-        const unsigned d2 = (kx >> shift2) & (kRadix - 1);
-        atomicAdd(&L.h2[((pos >= L.bnd[d] ? 16u : 0u) + d) * 16u + d2], 1u);
+      // every earlier pass): my left neighbour's may not exceed mine.  The neighbour's key comes over DPP (wave_shr:1;
+      // lane 0 keeps the 0).  Checked on four of the sixteen 512-key bands of the tile: three vector instructions per
+      // checked key in a VALU-bound kernel — all sixteen cost 10 % of the pass (28.1 -> 31.4 us at 2^24 keys), an
+      // unstable rank is a property of the hardware and shows in any band.
+      if (DBHIP_RS_CHECK_MOD != 0 && k % (DBHIP_RS_CHECK_MOD ? DBHIP_RS_CHECK_MOD : 1) == 0) {
+        const unsigned mine = kx & low_mask;
+        const unsigned left = __builtin_amdgcn_update_dpp(0u, mine, 0x138, 0xf, 0xf, false);
+        bad |= left > mine ? 1u : 0u;
       }
+      const unsigned d = (kx >> shift) & (kRadix - 1);
+      dst[L.goff[d] + p] = kk;
     }
   }
   __syncthreads();
@@ -589,13 +664,18 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   __shared__ unsigned s_cnt[kRsWaves][kRadix];
   __shared__ unsigned s_dexcl[kRadix];
   __shared__ unsigned s_goff[kRadix];
-  __shared__ unsigned s_wsum[kRsWaves];
+  __shared__ unsigned s_wsum[kRsWaves], s_wsum2[kRsWaves];
   __shared__ unsigned s_keys[kRsTile];
-  __shared__ unsigned s_bnd[BITS == 4 ? 16 : 1], s_c0[BITS == 4 ? 16 : 1];
+  __shared__ unsigned s_bnd[BITS == 4 ? 16 : 1], s_c0[BITS == 4 ? 16 : 1], s_thr[BITS == 4 ? 16 : 1];
   __shared__ unsigned s_h2[BITS == 4 ? 512 : 1];
-  const RsLds<BITS> L{s_cnt, s_dexcl, s_goff, s_wsum, s_keys, s_bnd, s_h2};
+  const RsLds<BITS> L{s_cnt, s_dexcl, s_goff, s_wsum, s_wsum2, s_keys, s_bnd, s_thr, s_h2};
 
-  const unsigned varying = hdr->or_bits & hdr->nor_bits;
+#if defined(DBHIP_RS_DIAG) && (DBHIP_RS_DIAG & 4)
+  const unsigned varying = 0xFFFFFFFFu;
+  if (hdr->status == 12345u) return;
+#else
+  const unsigned varying = rs_varying(hdr);
+#endif
   if (!rs_varies<BITS>(varying, pass)) return;  // uniform over the grid
   const unsigned par = rs_parity<BITS>(varying, pass);
   const unsigned *__restrict__ src = par ? tmp : keys;
@@ -605,7 +685,7 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   const int shift2 = next >= 0 ? next * BITS : -1;
   const unsigned low_mask = shift + BITS >= 32 ? 0xFFFFFFFFu : (1u << (shift + BITS)) - 1u;
 
-  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned tid = threadIdx.x;
   // XCD-aware chunk order (speed only): workgroups go to the 8 XCDs round-robin by blockIdx; XCD x takes the x-th
   // eighth of the chunks, so neighbouring chunks — whose digit runs are neighbours in the output and share the
   // partial lines at their ends — are written through the same L2.
@@ -617,9 +697,8 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   size_t last_tile = first_tile + tiles_per_chunk;
   last_tile = last_tile < total_tiles ? last_tile : total_tiles;
   // digit owners keep the chunk's running global offset of their digit in a register
-  unsigned running = 0;
+  unsigned running = 0, total = 0;
   if (BITS == 8) {
-    unsigned total = 0;
     if (tid < kRadix) {
       const unsigned *row = offsets + static_cast<size_t>(tid) * num_chunks;
       if (fused_scan) {
@@ -630,17 +709,13 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
         }
       } else {
         running = row[chunk];
+#if !(defined(DBHIP_RS_DIAG) && (DBHIP_RS_DIAG & 2))
         total = totals[pass * kRsMaxRadix + tid];
+#endif
       }
     }
-    // digit base = exclusive scan of the 256 totals (threads 0..255 = waves 0..3)
-    const unsigned incl = wave_inclusive_scan(total);
-    if (lane == kWave - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned base = incl - total;
-    for (unsigned w = 0; w < wave; ++w) base += s_wsum[w];
-    running += base;
-    __syncthreads();  // s_wsum is reused by the tiles
+    // (the digit base = exclusive scan of the 256 totals is added inside the first tile: done here it put a dependent
+    //  global load and two barriers in front of the tile's key loads, 28 -> 35 us per pass at 2^24 keys)
   } else {
     const size_t chunk_keys = tiles_per_chunk * kRsTile;
     if (tid < kRadix) {
@@ -664,23 +739,32 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   for (size_t tile = first_tile; tile < last_tile; ++tile) {
     const size_t tile_base = tile * kRsTile;
     const unsigned valid_in_tile = static_cast<unsigned>(n - tile_base < kRsTile ? n - tile_base : kRsTile);
+#if defined(DBHIP_RS_DIAG) && (DBHIP_RS_DIAG & 1)
+    const bool inj = false;
+#else
     const bool inj = inject != 0 && tile == 0;
+#endif
+#if defined(DBHIP_RS_DIAG) && (DBHIP_RS_DIAG & 2)
+    const bool first = false;
+#else
+    const bool first = BITS == 8 && tile == first_tile;
+#endif
     if (valid_in_tile == kRsTile)  // every tile but the input's last one
       bad |= rs_scatter_tile<BITS, true, ARANK>(src, dst, tile_base, valid_in_tile, shift, shift2, xor_mask, low_mask, inj,
-                                                running, L);
+                                                first, total, running, L);
     else
       bad |= rs_scatter_tile<BITS, false, ARANK>(src, dst, tile_base, valid_in_tile, shift, shift2, xor_mask, low_mask, inj,
-                                                 running, L);
+                                                 first, total, running, L);
   }
   if (bad) atomicOr(&hdr->status, DBHIP_DEV_RANK_ORDER);
   if (BITS == 4 && shift2 >= 0) {
-    // the next pass's counts: table entry (w, d, d') belongs to chunk c0[d] + w of the next pass (the tiles' last barrier
-    // has ordered the table's atomics before these reads); 16 consecutive lanes add to 64 contiguous bytes
+    // the next pass's counts: table entry (d, d', w) belongs to chunk c0[d] + w of the next pass (the tiles' last barrier
+    // has ordered the table's atomics before these reads); 32 consecutive lanes add to two runs of 64 contiguous bytes
     unsigned *nc = next_counts + static_cast<size_t>(par ^ 1u) * num_chunks * 16;
     for (unsigned i = tid; i < 512; i += kRsThreads) {
       const unsigned v = s_h2[i];
-      const size_t c = static_cast<size_t>(s_c0[(i >> 4) & 15u]) + (i >> 8);
-      if (v && c < num_chunks) atomicAdd(&nc[c * 16 + (i & 15u)], v);
+      const size_t c = static_cast<size_t>(s_c0[i >> 5]) + (i & 1u);
+      if (v && c < num_chunks) atomicAdd(&nc[c * 16 + ((i >> 1) & 15u)], v);
     }
   }
 }
@@ -794,7 +878,7 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_finalize_kernel(unsigned *__restrict__ keys, const unsigned *__restrict__ tmp,
                                                                  size_t n, const RsHeader *hdr) {
-  if (!rs_parity<BITS>(hdr->or_bits & hdr->nor_bits, 32 / BITS)) return;  // an even number of passes ran
+  if (!rs_parity<BITS>(rs_varying(hdr), 32 / BITS)) return;  // an even number of passes ran
   const size_t stride = static_cast<size_t>(gridDim.x) * kRsThreads;
   const size_t n4 = n / 4;
   const u32x4 *s4 = reinterpret_cast<const u32x4 *>(tmp);
@@ -835,12 +919,13 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
   hipError_t e = fill_async(workspace, 0, kWsHeader, s);
   if (e != hipSuccess) return static_cast<int>(e);
 
-  const size_t cap = static_cast<size_t>(dev.cus) * 4;
   const size_t want = (n / 4 + kRsThreads - 1) / kRsThreads;
-  const unsigned fgrid = static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+  const size_t fcap = static_cast<size_t>(dev.cus) * 2;  // (after an even number of passes its workgroups return at once)
+  const unsigned fgrid = static_cast<unsigned>(want < fcap ? (want ? want : 1) : fcap);
   constexpr int kCpw = rs_hist_cpw<BITS>();
   const size_t hist_groups = (g.chunks + kCpw - 1) / kCpw;
-  const unsigned hist_grid = static_cast<unsigned>(hist_groups < cap ? hist_groups : cap);
+  const size_t ucap = static_cast<size_t>(dev.cus) * 2;  // persistent: one header atomic per workgroup (see rs_upfront_kernel)
+  const unsigned hist_grid = static_cast<unsigned>(hist_groups < ucap ? hist_groups : ucap);
   const unsigned cgrid = static_cast<unsigned>(g.chunks);
   const unsigned sgrid = (cgrid + 7) / 8 * 8;
   if (BITS == 8) {
@@ -869,8 +954,9 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
     unsigned *off = cnt2 + 2 * 16 * g.chunks;
     hipLaunchKernelGGL((rs_upfront_kernel<BITS>), dim3(hist_grid), dim3(kRsThreads), 0, s, keys, n, xor_mask, hdr, cnt2,
                        g.tiles_per_chunk, g.chunks);
-    hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS, true>), dim3(cgrid), dim3(kRsThreads), 0, s, keys, tmp, n, 0, xor_mask, hdr,
-                       cnt2, g.tiles_per_chunk, g.chunks);
+    // (does something only when digit 0 is constant; a grid of one workgroup per CU returns in ~2 us, 1024 take ~5)
+    hipLaunchKernelGGL((rs_chunk_hist_kernel<BITS, true>), dim3(cgrid < static_cast<unsigned>(dev.cus) ? cgrid : dev.cus),
+                       dim3(kRsThreads), 0, s, keys, tmp, n, 0, xor_mask, hdr, cnt2, g.tiles_per_chunk, g.chunks);
     for (int p = 0; p < kPasses; ++p) {
       hipLaunchKernelGGL(rs_scan4_kernel, dim3(1), dim3(1024), 0, s, p, hdr, cnt2, off, g.chunks);
       if (arank)
