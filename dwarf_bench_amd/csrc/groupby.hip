@@ -14,6 +14,17 @@
 //                 only range r of chunk x — partner workgroups read the same rows at about the same
 //                 time, so the second read is served by L2 / Infinity Cache, not HBM.  Few groups:
 //                 the table is replicated across lanes (odd stride) to spread same-address ds_add.
+//                 More than 32768 groups (round 3): TWO groups per LDS word, 16 bits each — a 128 KiB
+//                 table then holds 65536 groups and BASELINE's 2^16-group configuration reads every row
+//                 once instead of twice.  The word is one 32-bit accumulator of L + 65536 * H (L, H: the
+//                 sums of the even and the odd group) fed by RETURNING ds_add: from the returned value a
+//                 lane sees exactly whether its add carried out of the low half (K16 events) or out of
+//                 bit 31 (K32 events), so L = low half + 65536 * K16 and H = high half + 65536 * K32 - K16
+//                 (mod 2^32) whatever the interleaving.  The events are rare for value ranges like the
+//                 reference's [1, 10000] (a workgroup sees about four rows per group) and go, with the
+//                 part of a value above 16 bits, to a spill table in global memory by memory-side
+//                 atomics; gb_reduce adds it.  Values that carry on most rows make this path slow
+//                 (two global atomics per carry), never wrong.
 //   gb_reduce     sums the per-workgroup partial tables into output[] (plain coalesced loads, no
 //                 global atomics: memory-side atomics are ~5x slower than stores on this chip).
 //
@@ -23,7 +34,8 @@
 namespace dbhip {
 namespace {
 
-constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table
+constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table of 32-bit sums
+constexpr int kGbMaxPackedGroups = 2 * kGbMaxLdsGroups;  // the same 128 KiB with two 16-bit partial sums per word
 constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table is large
 #ifndef DBHIP_GB_VEC
 #define DBHIP_GB_VEC 2
@@ -49,14 +61,22 @@ struct GbGeometry {
   unsigned threads;      // workgroup size
   unsigned chunk_slots;  // workgroups per range = partial tables per range
   unsigned lds_words;
+  unsigned packed;       // two groups per LDS word (more than kGbMaxLdsGroups groups)
+  unsigned part_words;   // words of one partial table
 };
 
 inline GbGeometry gb_geometry(uint32_t groups, int cus) {
   GbGeometry g;
-  g.ranges = (groups + kGbMaxLdsGroups - 1) / kGbMaxLdsGroups;
+  g.packed = groups > static_cast<uint32_t>(kGbMaxLdsGroups) ? 1u : 0u;
+#ifdef DBHIP_GB_NO_PACKED  // A/B knob: round 2's two-ranges-of-32-bit-sums path
+  g.packed = 0;
+#endif
+  const uint32_t cap = g.packed ? kGbMaxPackedGroups : kGbMaxLdsGroups;
+  g.ranges = (groups + cap - 1) / cap;
   if (g.ranges == 0) g.ranges = 1;
   g.range_groups = (groups + g.ranges - 1) / g.ranges;
   if (g.range_groups == 0) g.range_groups = 1;
+  if (g.packed) g.range_groups = (g.range_groups + 1u) & ~1u;  // a word's two groups belong to one range
   // Few groups: same-address ds_add serialises, so the table is replicated and lane l adds into copy
   // l % replicas.  The copies are an ODD number of words apart: a stride that is a multiple of the 32
   // LDS banks (64 groups!) would put the same key of every copy on one bank and undo the spreading.
@@ -64,6 +84,12 @@ inline GbGeometry gb_geometry(uint32_t groups, int cus) {
   while (g.replicas > 1 && (g.range_groups | 1u) * g.replicas > static_cast<unsigned>(kGbMaxLdsGroups)) g.replicas /= 2;
   g.rep_stride = g.replicas > 1 ? (g.range_groups | 1u) : g.range_groups;
   g.lds_words = g.rep_stride * g.replicas;
+  if (g.packed) {
+    g.replicas = 1;
+    g.rep_stride = g.range_groups / 2;
+    g.lds_words = g.range_groups / 2;
+  }
+  g.part_words = g.packed ? g.range_groups / 2 : g.range_groups;
   // one 16-wave workgroup per CU for every table size: a few hundred partial tables keep gb_reduce short
   g.threads = kGbBigThreads;
   unsigned total = static_cast<unsigned>(cus);
@@ -72,11 +98,22 @@ inline GbGeometry gb_geometry(uint32_t groups, int cus) {
   return g;
 }
 
-template <int THREADS, bool kShared>
+// the rare path of the packed table: carries and the part of a value above 16 bits go to the spill table
+__device__ __noinline__ void gb_spill(unsigned *spill, unsigned groups, unsigned key, unsigned val, bool carry32, bool carry16) {
+  const unsigned even = key & ~1u, odd = key | 1u;
+  if (val >> 16) atomicAdd(&spill[key], val & 0xFFFF0000u);
+  if (carry16) {  // out of the low half: 65536 more for the even group, and the odd group's half holds one too many
+    atomicAdd(&spill[even], 65536u);
+    if (odd < groups) atomicAdd(&spill[odd], 0xFFFFFFFFu);
+  }
+  if (carry32 && odd < groups) atomicAdd(&spill[odd], 65536u);  // out of bit 31
+}
+
+template <int THREADS, bool kShared, bool PACKED>
 __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
     const u32x4 *__restrict__ keys4, const u32x4 *__restrict__ vals4, const unsigned *__restrict__ keys,
     const unsigned *__restrict__ vals, size_t n, unsigned groups, GbGeometry geo,
-    unsigned *__restrict__ partials, GbHeader *hdr) {
+    unsigned *__restrict__ partials, unsigned *spill, GbHeader *hdr) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_table[];
   const unsigned tid = threadIdx.x;
   // blocks b and b+8 tend to share an XCD (round-robin dispatch): give them the same rows and
@@ -122,6 +159,14 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
       }
     }
   };
+  auto add_packed = [&](unsigned key, unsigned rel, unsigned val) {
+    const unsigned sh = (rel & 1u) << 4;
+    const unsigned a = (val & 0xFFFFu) << sh;
+    const unsigned old = atomicAdd(&s_table[rel >> 1], a);  // returning: the lane sees what its add did
+    const bool carry32 = old + a < old;
+    const bool carry16 = sh == 0 && (old & 0xFFFFu) + a > 0xFFFFu;
+    if (carry32 || carry16 || (val >> 16)) gb_spill(spill, groups, key, val, carry32, carry16);
+  };
   auto add_step = [&](size_t base, const u32x4 (&k)[kGbVecPerIter], const u32x4 (&v)[kGbVecPerIter]) {
 #pragma unroll
     for (int u = 0; u < kGbVecPerIter; ++u) {
@@ -131,7 +176,11 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned rel = kk[c] - lo;
-        if (rel < span) atomicAdd(&s_table[rep_off + rel], vv[c]);
+        if (PACKED) {
+          if (rel < span) add_packed(kk[c], rel, vv[c]);
+        } else if (rel < span) {
+          atomicAdd(&s_table[rep_off + rel], vv[c]);
+        }
         bad_key |= live && kk[c] >= groups;
       }
     }
@@ -159,14 +208,22 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
   if (slot == 0 && tid < (n & 3)) {
     const unsigned kk = keys[n4 * 4 + tid], vv = vals[n4 * 4 + tid];
     const unsigned rel = kk - lo;
-    if (rel < span) atomicAdd(&s_table[rep_off + rel], vv);
+    if (PACKED) {
+      if (rel < span) add_packed(kk, rel, vv);
+    } else if (rel < span) {
+      atomicAdd(&s_table[rep_off + rel], vv);
+    }
     bad_key |= kk >= groups;
   }
   if (bad_key && range == 0) atomicOr(&hdr->status, DBHIP_DEV_KEY_RANGE);
   __syncthreads();
 
-  // partial table of this workgroup: partials[range][slot][range_groups]
-  unsigned *dst = partials + (static_cast<size_t>(range) * geo.chunk_slots + slot) * geo.range_groups;
+  // partial table of this workgroup: partials[range][slot][part_words] (packed: the LDS words as they are)
+  unsigned *dst = partials + (static_cast<size_t>(range) * geo.chunk_slots + slot) * geo.part_words;
+  if (PACKED) {
+    for (unsigned w = tid; w < geo.part_words; w += THREADS) dst[w] = s_table[w];
+    return;
+  }
   for (unsigned g = tid; g < geo.range_groups; g += THREADS) {
     unsigned sum = 0;
     for (unsigned r = 0; r < geo.replicas; ++r) sum += s_table[r * geo.rep_stride + g];
@@ -201,12 +258,54 @@ __global__ __launch_bounds__(256) void gb_reduce_kernel(const unsigned *__restri
   if (wave == 0 && g < groups) out[g] = s_sum[0][lane] + s_sum[1][lane] + s_sum[2][lane] + s_sum[3][lane];
 }
 
+// packed partial tables: one thread per WORD = two groups; the spill table holds the carries and the upper value bits
+__global__ __launch_bounds__(256) void gb_reduce_packed_kernel(const unsigned *__restrict__ partials, const unsigned *__restrict__ spill,
+                                                               GbGeometry geo, unsigned groups, unsigned *__restrict__ out) {
+  __shared__ unsigned s_lo[4][kWave], s_hi[4][kWave];
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const unsigned word = blockIdx.x * kWave + lane;  // over ranges * part_words
+  const unsigned range = word / geo.part_words, rel = word % geo.part_words;
+  const unsigned g0 = range * geo.range_groups + 2 * rel;
+  unsigned lo = 0, hi = 0;
+  if (range < geo.ranges && g0 < groups) {
+    const unsigned *p = partials + static_cast<size_t>(range) * geo.chunk_slots * geo.part_words + rel;
+    unsigned s = wave;
+    for (; s + 28 < geo.chunk_slots; s += 32) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(s + 4 * u) * geo.part_words];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lo += v[u] & 0xFFFFu;
+        hi += v[u] >> 16;
+      }
+    }
+    for (; s < geo.chunk_slots; s += 4) {
+      const unsigned v = p[static_cast<size_t>(s) * geo.part_words];
+      lo += v & 0xFFFFu;
+      hi += v >> 16;
+    }
+  }
+  s_lo[wave][lane] = lo;
+  s_hi[wave][lane] = hi;
+  __syncthreads();
+  if (wave == 0 && range < geo.ranges && g0 < groups) {
+    out[g0] = s_lo[0][lane] + s_lo[1][lane] + s_lo[2][lane] + s_lo[3][lane] + spill[g0];
+    if (g0 + 1 < groups && 2 * rel + 1 < geo.range_groups)
+      out[g0 + 1] = s_hi[0][lane] + s_hi[1][lane] + s_hi[2][lane] + s_hi[3][lane] + spill[g0 + 1];
+  }
+}
+
 }  // namespace
 }  // namespace dbhip
 
 using namespace dbhip;
 
 namespace {
+// workspace: header | spill[groups] (packed tables only; cleared with the header) | partial tables
+size_t gb_spill_bytes(const GbGeometry &geo, uint32_t groups) {
+  return geo.packed ? align_up(static_cast<size_t>(groups) * sizeof(unsigned), kWsAlign) : 0;
+}
 // geometry for a launch: `max_tables` (0 = no limit) caps the number of private tables per key range —
 // the reference's `executors` knob of GroupByLocal (groupby/groupby_local.cpp:27, :58-83)
 GbGeometry gb_launch_geometry(uint32_t groups, uint32_t max_tables, int cus) {
@@ -228,30 +327,31 @@ int gb_partial(const uint32_t *keys, const uint32_t *vals, size_t n, uint32_t gr
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   const GbGeometry geo = gb_launch_geometry(groups, max_tables, dev.cus);
-  const size_t partial_words = static_cast<size_t>(geo.ranges) * geo.chunk_slots * geo.range_groups;
-  if (!ws_ok(workspace, workspace_bytes, kWsHeader + partial_words * sizeof(unsigned))) return DBHIP_EWORKSPACE;
+  const size_t partial_words = static_cast<size_t>(geo.ranges) * geo.chunk_slots * geo.part_words;
+  const size_t spill_bytes = gb_spill_bytes(geo, groups);
+  if (!ws_ok(workspace, workspace_bytes, kWsHeader + spill_bytes + partial_words * sizeof(unsigned))) return DBHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
-  hipError_t e = fill_async(workspace, 0, kWsHeader, s);
+  hipError_t e = fill_async(workspace, 0, kWsHeader + spill_bytes, s);
   if (e != hipSuccess) return static_cast<int>(e);
   GbHeader *hdr = static_cast<GbHeader *>(workspace);
-  unsigned *partials = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + kWsHeader);
+  unsigned *spill = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + kWsHeader);
+  unsigned *partials = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + kWsHeader + spill_bytes);
   const unsigned grid = geo.ranges * geo.chunk_slots;
   const size_t lds = static_cast<size_t>(geo.lds_words) * sizeof(unsigned);
   const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys), *v4 = reinterpret_cast<const u32x4 *>(vals);
-  if (geo.ranges > 2) {  // measured: plain (L2-allocating) loads win from 4 readers per row on, nt below
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (kGbMaxLdsGroups + 32) * 4);
+  auto launch = [&](auto kernel) -> int {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (kGbMaxLdsGroups + 32) * 4);
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads, true>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
-                       v4, keys, vals, n, groups, geo, partials, hdr);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gb_aggregate_kernel<kGbBigThreads, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (kGbMaxLdsGroups + 32) * 4);
-    if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL((gb_aggregate_kernel<kGbBigThreads, false>), dim3(grid), dim3(kGbBigThreads), lds, s, k4,
-                       v4, keys, vals, n, groups, geo, partials, hdr);
-  }
-  return launch_status();
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kGbBigThreads), lds, s, k4, v4, keys, vals, n, groups, geo, partials, spill,
+                       hdr);
+    return launch_status();
+  };
+  // measured: plain (L2-allocating) loads win from 4 readers per row on, nt below
+  if (geo.packed) return geo.ranges > 2 ? launch(gb_aggregate_kernel<kGbBigThreads, true, true>)
+                                        : launch(gb_aggregate_kernel<kGbBigThreads, false, true>);
+  return geo.ranges > 2 ? launch(gb_aggregate_kernel<kGbBigThreads, true, false>)
+                        : launch(gb_aggregate_kernel<kGbBigThreads, false, false>);
 }
 
 int gb_merge(uint32_t groups, uint32_t max_tables, uint32_t *out, const void *workspace, dbhip_stream_t stream) {
@@ -260,9 +360,17 @@ int gb_merge(uint32_t groups, uint32_t max_tables, uint32_t *out, const void *wo
   const DeviceInfo &dev = current_device_info();
   if (!dev.ok) return DBHIP_ENODEVICE;
   const GbGeometry geo = gb_launch_geometry(groups, max_tables, dev.cus);
-  const unsigned *partials = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) + kWsHeader);
-  hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, as_stream(stream), partials,
-                     geo, groups, out);
+  const size_t spill_bytes = gb_spill_bytes(geo, groups);
+  const unsigned *spill = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) + kWsHeader);
+  const unsigned *partials = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) + kWsHeader + spill_bytes);
+  if (geo.packed) {
+    const size_t words = static_cast<size_t>(geo.ranges) * geo.part_words;
+    hipLaunchKernelGGL(gb_reduce_packed_kernel, dim3(static_cast<unsigned>((words + kWave - 1) / kWave)), dim3(256), 0,
+                       as_stream(stream), partials, spill, geo, groups, out);
+  } else {
+    hipLaunchKernelGGL(gb_reduce_kernel, dim3((groups + kWave - 1) / kWave), dim3(256), 0, as_stream(stream), partials,
+                       geo, groups, out);
+  }
   return launch_status();
 }
 }  // namespace
@@ -271,8 +379,8 @@ extern "C" size_t dbhip_groupby_sum_u32_workspace_bytes(size_t n, uint32_t group
   (void)n;
   // sized for the largest device this library targets (256 CUs) so the query needs no device
   const GbGeometry g = gb_geometry(groups ? groups : 1, 256);
-  const size_t partial_words = static_cast<size_t>(g.ranges) * g.chunk_slots * g.range_groups;
-  return align_up(kWsHeader + partial_words * sizeof(unsigned), kWsAlign);
+  const size_t partial_words = static_cast<size_t>(g.ranges) * g.chunk_slots * g.part_words;
+  return align_up(kWsHeader + gb_spill_bytes(g, groups ? groups : 1) + partial_words * sizeof(unsigned), kWsAlign);
 }
 
 extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals, size_t n,

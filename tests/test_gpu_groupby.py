@@ -37,6 +37,28 @@ def test_wraparound_sums():
     assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
 
 
+@pytest.mark.parametrize("groups", [32769, 65535, 65536, 65537, 131072 + 5, 300001])
+@pytest.mark.parametrize("vals_kind", ["reference", "carry_often", "full_range", "all_ones_16", "skew_one_pair"])
+def test_packed_table_two_groups_per_lds_word(groups, vals_kind):
+    """More than 32768 groups: two 16-bit partial sums per LDS word, carries (out of the low half, out of bit 31) and value
+    bits above 16 go to the spill table.  Value ranges that never, sometimes and always carry; group counts at the table
+    boundaries, odd, and over several key ranges; uint32 wrap-around exact against expected_GroupBy restated."""
+    n = 400003
+    keys = po.gen_uniform_u32(n, 21, 0, groups - 1)
+    if vals_kind == "reference":
+        vals = po.gen_uniform_u32(n, 22, 1, 10000)
+    elif vals_kind == "carry_often":
+        vals = po.gen_uniform_u32(n, 22, 30000, 65535)
+    elif vals_kind == "full_range":
+        vals = po.gen_uniform_u32(n, 22, 0, 2**32 - 1)
+    elif vals_kind == "all_ones_16":
+        vals = np.full(n, 0xFFFF, np.uint32)
+    else:  # every row on one word's two groups: both halves carry all the time, and into each other
+        keys = (np.arange(n, dtype=np.uint32) & 1) + np.uint32(groups - 2 - (groups & 1))
+        vals = po.gen_uniform_u32(n, 22, 0xFF00, 0x1FFFF)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
 def test_skewed_keys():
     n, groups = 1 << 18, 65536
     keys = np.zeros(n, np.uint32)
