@@ -162,6 +162,113 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const un
   for (unsigned i = threadIdx.x; i < parts; i += kJlFusedThreads) mine[i] = s_hist[i];
 }
 
+// ---- the same for 32768 < parts <= 65536 (2^27-row shards: what every rank of the 8-GPU join partitions) ----------------
+// 65536 32-bit counters do not fit the LDS; 16 bits are enough for a workgroup's share of a partition (2^27 rows / 256
+// workgroups / 65536 partitions = 8 rows) unless the input is heavily skewed.  TWO counters per LDS word, fed by
+// RETURNING ds_add: from the returned value a lane sees exactly when its increment carried out of the low half (the
+// even partition's counter wrapped and the odd one's now holds one too many) or out of bit 31 (the odd one wrapped) and
+// settles that in the global accumulators the reduce kernel adds to — correct for any input, and free for every input
+// that is not pathological.  The workgroup's row of wgcnt is the LDS image: parts / 2 words.
+__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const unsigned *__restrict__ keys, size_t n,
+                                                                          unsigned parts, unsigned log2_k2, unsigned k1,
+                                                                          unsigned *__restrict__ wgcnt,
+                                                                          unsigned long long *counts0g,
+                                                                          unsigned long long *counts1) {
+  extern __shared__ unsigned s_hist[];
+  const unsigned group = blockIdx.x / kJlFusedWgPerGroup, w = blockIdx.x % kJlFusedWgPerGroup;
+  const unsigned words = parts / 2;
+  for (unsigned i = threadIdx.x; i < words; i += kJlFusedThreads) s_hist[i] = 0;
+  __syncthreads();
+  auto count = [&](unsigned key) {
+    const unsigned p = jl_pid(key, parts);
+    const unsigned inc = 1u << ((p & 1u) << 4);
+    const unsigned old = atomicAdd(&s_hist[p >> 1], inc);
+    const bool carry16 = (p & 1u) == 0 && (old & 0xFFFFu) == 0xFFFFu, carry32 = old + inc < old;
+    if (carry16 || carry32) {  // (more than 65535 rows of this workgroup's share in one partition)
+      const unsigned even = p & ~1u, odd = p | 1u;
+      unsigned long long *g0 = counts0g + static_cast<size_t>(group) * k1;
+      if (carry16) {
+        atomicAdd(&counts1[even], 65536ull);
+        atomicAdd(&g0[even >> log2_k2], 65536ull);
+        atomicAdd(&counts1[odd], ~0ull);  // minus one: the carry landed in the odd partition's half
+        atomicAdd(&g0[odd >> log2_k2], ~0ull);
+      }
+      if (carry32) {
+        atomicAdd(&counts1[odd], 65536ull);
+        atomicAdd(&g0[odd >> log2_k2], 65536ull);
+      }
+    }
+  };
+  const size_t tpg = jl_tiles_per_group(n);
+  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
+  size_t hi = lo + tpg * kJlTile;
+  hi = hi < n ? hi : n;
+  if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
+    const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
+    const size_t n4 = (hi - lo) / 4;
+    for (size_t i = static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < n4;
+         i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = i + j * kJlFusedThreads < n4 ? k4[i + j * kJlFusedThreads] : u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j * kJlFusedThreads < n4) {
+          count(v[j].x);
+          count(v[j].y);
+          count(v[j].z);
+          count(v[j].w);
+        }
+    }
+    if (w == 0 && lo + n4 * 4 + threadIdx.x < hi) count(keys[lo + n4 * 4 + threadIdx.x]);
+  } else {
+    for (size_t i = lo + static_cast<size_t>(w) * kJlFusedThreads + threadIdx.x; i < hi;
+         i += static_cast<size_t>(kJlFusedWgPerGroup) * kJlFusedThreads)
+      count(keys[i]);
+  }
+  __syncthreads();
+  unsigned *mine = wgcnt + static_cast<size_t>(blockIdx.x) * words;
+  for (unsigned i = threadIdx.x; i < words; i += kJlFusedThreads) mine[i] = s_hist[i];
+}
+
+// reduce of the packed rows; ADDS to counts1 / counts0g (zeroed with the metadata, and possibly holding the carries
+// the histogram kernel settled): one thread per WORD (two partitions) for the column sums, one wave per (row, bucket)
+// for the level-0 counts — the sum of both halves of a bucket's words
+__global__ __launch_bounds__(256) void jl_hist_reduce16_kernel(const unsigned *__restrict__ wgcnt, unsigned parts, unsigned k1,
+                                                               unsigned k2, unsigned long long *counts0g,
+                                                               unsigned long long *counts1) {
+  constexpr unsigned kRows = kJlGroups * kJlFusedWgPerGroup;
+  const unsigned words = parts / 2, col_blocks = (words + 255) / 256;
+  if (blockIdx.x < col_blocks) {
+    const unsigned wd = blockIdx.x * 256 + threadIdx.x;
+    if (wd >= words) return;
+    unsigned long long lo = 0, hi = 0;
+    for (unsigned r0 = 0; r0 < kRows; r0 += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wgcnt[static_cast<size_t>(r0 + u) * words + wd];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lo += v[u] & 0xFFFFu;
+        hi += v[u] >> 16;
+      }
+    }
+    counts1[2 * wd] += lo;  // (the histogram kernel has finished: no one else touches these words now)
+    counts1[2 * wd + 1] += hi;
+    return;
+  }
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const size_t item = static_cast<size_t>(blockIdx.x - col_blocks) * 4 + wave;  // (row, bucket)
+  if (item >= static_cast<size_t>(kRows) * k1) return;
+  const unsigned row = static_cast<unsigned>(item / k1), bucket = static_cast<unsigned>(item % k1);
+  const unsigned *src = wgcnt + static_cast<size_t>(row) * words + static_cast<size_t>(bucket) * (k2 / 2);
+  unsigned mine = 0;
+  for (unsigned sub = lane; sub < k2 / 2; sub += kWave) mine += (src[sub] & 0xFFFFu) + (src[sub] >> 16);
+  mine = wave_reduce_add(mine);
+  if (lane == kWave - 1 && mine)
+    atomicAdd(&counts0g[static_cast<size_t>(row / kJlFusedWgPerGroup) * k1 + bucket], static_cast<unsigned long long>(mine));
+}
+
 // counts1[p] = rows of partition p (column sums of wgcnt, one thread per partition: the first parts/256 workgroups),
 // counts0g[g][b] = rows of group g in level-0 bucket b (one WAVE per (workgroup row, bucket): k2 contiguous counters,
 // added to the zeroed counts0g with one atomic per wave: the remaining workgroups)
@@ -1052,7 +1159,23 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   // output region, written only later by the level-1 scatter)
   // (8192..32768 partitions = 2^24..2^26 rows: level below it the two plain histograms are as fast, 2^22 rows: 77 vs 80 us)
   const bool fused = k2 > 1 && parts >= 8192 && parts <= kJlFusedMaxParts && fused_scratch != nullptr;
-  if (fused) {
+  // 32768 < parts <= 65536 (2^27-row shards): the same with two 16-bit counters per LDS word (jl_hist_fused16_kernel)
+#ifdef DBHIP_JL_NO_FUSED16  // A/B knob: the two plain histograms for these sizes, as in round 2
+  const bool fused16 = false;
+#else
+  const bool fused16 = !fused && k2 > 1 && kJlFusedMaxParts != 0 && parts > kJlFusedMaxParts && parts <= 2 * kJlFusedMaxParts &&
+                       fused_scratch != nullptr;
+#endif
+  if (fused16) {
+    const size_t lds = static_cast<size_t>(parts / 2) * sizeof(unsigned);
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_hist_fused16_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (ea != hipSuccess) return static_cast<int>(ea);
+    hipLaunchKernelGGL(jl_hist_fused16_kernel, dim3(kJlGroups * kJlFusedWgPerGroup), dim3(kJlFusedThreads), lds, s, keys, n,
+                       parts, log2_k2, k1, fused_scratch, counts0, counts1);
+    const unsigned red_grid = (parts / 2 + 255) / 256 + (kJlGroups * kJlFusedWgPerGroup * k1 + 3) / 4;
+    hipLaunchKernelGGL(jl_hist_reduce16_kernel, dim3(red_grid), dim3(256), 0, s, fused_scratch, parts, k1, k2, counts0, counts1);
+  } else if (fused) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_hist_fused_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(parts * sizeof(unsigned)));
     if (ea != hipSuccess) return static_cast<int>(ea);
@@ -1078,7 +1201,7 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   if (k2 > 1) {
     const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + k1);
     const size_t lds1 = jl_scatter_lds_bytes(k2);
-    if (!fused)
+    if (!fused && !fused16)
       hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
                          rows_a, starts0, parts, k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,

@@ -92,7 +92,9 @@ class CopyIfLt:
         self._seen: dict[int, float] = {}
         self._last_filter = None
 
-    DENSE_ABOVE = 0.1  # selectivity from which the single-launch dense variant is the faster one (2^28 rows: 255 vs 260-275 us)
+    # selectivity from which the single-launch dense variant is the faster one.  2^28 rows, same box (tools/ab.py scan):
+    # s = 2.5 % two-launch 220 / dense 240 us, 5 % 242 / 240, 7.5 % 255 / 241, 10 % 265 / 242 — the two cross at about 4.5 %
+    DENSE_ABOVE = 0.05
 
     def launch(self, src: torch.Tensor, filter_value: int, dense: bool | None = None) -> None:
         """Asynchronous on the current stream; nothing is read back.  dense: True / False pick the variant

@@ -104,6 +104,27 @@ def test_join_baseline_config_2_26_properties():
         assert np.array_equal(a, np.sort(oids[int(opos[i]): int(opos[i] + ocnt[i])])), i
 
 
+def test_join_2_27_rows_skewed_keys_through_the_packed_histogram():
+    """2^26 < n <= 2^27 build rows (the shard size of every rank of the 8-GPU join): both partition levels' histograms come
+    from one read of the keys with two 16-bit counters per LDS word.  Half of the build rows carry ONE key, so a
+    workgroup's share of that key's partition (2^18 rows) wraps its 16-bit counter several times: the carries are
+    settled in the global accumulators.  Counts per probe row against numpy, ids a permutation that really matches."""
+    from dwarf_bench_amd import ops
+    n, m = (1 << 26) + 12345, 1 << 20
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    build[::2] = 123456789  # every other row
+    probe = ops.gen_uniform_u32(m, 43, 0, n - 1)
+    probe[::1000] = 123456789
+    pos, cnt, ids = ops.hash_join(build, probe)
+    hb, hp = build.cpu().numpy().view(np.uint32), probe.cpu().numpy().view(np.uint32)
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint32).astype(np.uint64), po.join_counts_fast(hb, hp))
+    assert int(ids.to(torch.int64).sum().item()) == n * (n - 1) // 2  # a permutation of the build rows (sum of 0..n-1)
+    hit = cnt > 0
+    p, c = pos[hit].to(torch.int64), cnt[hit].to(torch.int64)
+    assert torch.equal(build[ids[p].to(torch.int64)], probe[hit])
+    assert torch.equal(build[ids[p + c - 1].to(torch.int64)], probe[hit])
+
+
 def test_ujoin_reference_fixture_shape(golden_dir):
     """unique-key payload join vs seq_join (join_helpers.hpp:86-104) as a multiset of rows (join.cpp:133)."""
     from dwarf_bench_amd import ops

@@ -58,7 +58,7 @@ def scan(_):
     n = 1 << 28
     src = ops.gen_uniform_u32(n, 42, 1, 10000)
     plan = ops.CopyIfLt(n)
-    for filt in (5, 101, 1001, 2501, 5001, 7501, 10001):
+    for filt in (5, 101, 251, 501, 751, 1001, 1501, 2001, 2501, 5001, 7501, 10001):
         t0 = median(times(lambda: plan.launch(src, filt, dense=False), 9))
         m = plan.result().numel()
         t1 = median(times(lambda: plan.launch(src, filt, dense=True), 9))
