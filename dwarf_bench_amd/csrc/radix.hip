@@ -39,7 +39,9 @@
 //     per-pass scan, digit bases added inside the scatter's first tile: up-front 29.7 + 4.6 -> 20.7 us, and every scatter
 //     2.7 us slower (28.2 -> 30.7 us; neither the order check, nor the skip logic, nor the fault hook — each compiled out
 //     in turn —, 35 % more VALU and 74 % more SALU instructions by the SQ counters but the kernel is bound by neither):
-//     207.3 us.  Two lessons kept: 512-1024 workgroups ending with two atomics on the SAME word are served one per ~11 ns
+//     207.3 us.  Isolated on round 2's code afterwards: a digit base that is loaded in the prologue and added inside the
+//     first tile costs 0.6 us per pass, added in the prologue itself (a use of a loaded value in front of the tile's key
+//     loads) 2.3 us; the rest is the 256-entry scan.  At best 5 us for the whole sort: not pursued.  Two lessons kept: 512-1024 workgroups ending with two atomics on the SAME word are served one per ~11 ns
 //     (the kernel then takes 34 us instead of 14), and a divide that consumes a loaded offset in the prologue puts that
 //     load's latency in front of the tile's key loads.
 // A single-pass Onesweep was re-examined on paper and not built: a dependent global round trip costs 2-4 us under load
