@@ -133,11 +133,17 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
   const unsigned span = hi_excl > lo ? hi_excl - lo : 0;
   const unsigned rep_off = (tid % geo.replicas) * geo.rep_stride;
 
-  for (unsigned i = tid; i < geo.lds_words; i += THREADS) s_table[i] = 0;
+  {  // clear the table: 16-byte LDS stores (the array is 16-byte aligned), the odd words at the end singly
+    u32x4 *t4 = reinterpret_cast<u32x4 *>(s_table);
+    for (unsigned i = tid; i < geo.lds_words / 4; i += THREADS) t4[i] = u32x4{0u, 0u, 0u, 0u};
+    for (unsigned i = (geo.lds_words & ~3u) + tid; i < geo.lds_words; i += THREADS) s_table[i] = 0;
+  }
   __syncthreads();
 
   bool bad_key = false;
   const size_t n4 = n / 4;
+  // (workgroups take every chunk_slots-th step of the columns; one contiguous slab per workgroup instead, as the reduce
+  //  kernel walks its input, measured the same within the +-3 us between runs, with 2 and with 4 loads per column in flight)
   const size_t step = static_cast<size_t>(geo.chunk_slots) * THREADS * kGbVecPerIter;
   // software pipeline: the loads of step i+1 are issued before the LDS atomics of step i (DBHIP_GB_PIPE=0 compiles
   // the plain load-then-add loop for A/B timing)
@@ -185,20 +191,20 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
       }
     }
   };
-  const size_t base0 = static_cast<size_t>(slot) * THREADS * kGbVecPerIter;
+  const size_t base0 = static_cast<size_t>(slot) * THREADS * kGbVecPerIter, n4_end = n4;
 #if DBHIP_GB_PIPE
   u32x4 ka[kGbVecPerIter], va[kGbVecPerIter], kb[kGbVecPerIter], vb[kGbVecPerIter];
-  if (base0 < n4) load_step(base0, ka, va);
-  for (size_t base = base0; base < n4; base += 2 * step) {
-    const bool has_b = base + step < n4;
+  if (base0 < n4_end) load_step(base0, ka, va);
+  for (size_t base = base0; base < n4_end; base += 2 * step) {
+    const bool has_b = base + step < n4_end;
     if (has_b) load_step(base + step, kb, vb);
     add_step(base, ka, va);
     if (!has_b) break;
-    if (base + 2 * step < n4) load_step(base + 2 * step, ka, va);
+    if (base + 2 * step < n4_end) load_step(base + 2 * step, ka, va);
     add_step(base + step, kb, vb);
   }
 #else
-  for (size_t base = base0; base < n4; base += step) {
+  for (size_t base = base0; base < n4_end; base += step) {
     u32x4 k[kGbVecPerIter], v[kGbVecPerIter];
     load_step(base, k, v);
     add_step(base, k, v);
@@ -220,8 +226,16 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_kernel(
 
   // partial table of this workgroup: partials[range][slot][part_words] (packed: the LDS words as they are)
   unsigned *dst = partials + (static_cast<size_t>(range) * geo.chunk_slots + slot) * geo.part_words;
-  if (PACKED) {
-    for (unsigned w = tid; w < geo.part_words; w += THREADS) dst[w] = s_table[w];
+  if (PACKED) {  // 16-byte non-temporal stores: the table is written once and read once, by gb_reduce
+    const unsigned w4 = geo.part_words / 4;  // (dst is 16-byte aligned: part_words is even and the tables start on 256-byte lines when it is a multiple of 4)
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+      const u32x4 *s4 = reinterpret_cast<const u32x4 *>(s_table);
+      u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+      for (unsigned w = tid; w < w4; w += THREADS) __builtin_nontemporal_store(s4[w], d4 + w);
+      for (unsigned w = w4 * 4 + tid; w < geo.part_words; w += THREADS) dst[w] = s_table[w];
+    } else {
+      for (unsigned w = tid; w < geo.part_words; w += THREADS) dst[w] = s_table[w];
+    }
     return;
   }
   for (unsigned g = tid; g < geo.range_groups; g += THREADS) {
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256) void gb_reduce_packed_kernel(const unsigned *_
     for (; s + 28 < geo.chunk_slots; s += 32) {
       unsigned v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(s + 4 * u) * geo.part_words];
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + static_cast<size_t>(s + 4 * u) * geo.part_words);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         lo += v[u] & 0xFFFFu;
