@@ -1207,7 +1207,10 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,
                        cursors1);
     // (one tile per workgroup; a persistent grid with the next tile's rows prefetched — what helps the level-0
-    //  scatter — measured the same here: a workgroup that ends after its stores never waits for them)
+    //  scatter — measured the same here: a workgroup that ends after its stores never waits for them.  Round 3: a
+    //  precomputed {bucket, tile} map in place of the workgroup's binary search over tile_starts — eight dependent
+    //  loads in front of its row loads — measured the same as well (partition of 2^26 rows 610 vs 615 us), and so did
+    //  the tile shapes 512x16 / 512x4 / 1024x4 once more (723 / 661 / 699 us against 610).)
     hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, rows_a, starts0, tstarts0,
                        parts, k1, k2, cursors1, rows_b);
     *out_pairs = reinterpret_cast<const unsigned *>(rows_b);
