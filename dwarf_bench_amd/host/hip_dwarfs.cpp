@@ -218,8 +218,8 @@ void run_scan(const char *who, size_t n, Meter &meter) {
     if (time_transfers() && n)
       hip_ok(hipMemcpy(src.get(), host_src.data(), n * sizeof(int32_t), hipMemcpyHostToDevice), "src H2D");
     hip_ok(hipEventRecord(ev.a, nullptr), "event");
-    // dense predicates (more than a twentieth of the rows matched in the previous iteration: where the two variants
-    // cross at 2^28 rows, tools/ab.py scan) take the single-launch variant
+    // dense predicates (more than 7.5 % of the rows matched in the previous iteration: the two variants cross between
+    // 5 % and 10 % at 2^28 rows, tools/ab.py scan) take the single-launch variant
     if (dense)
       db_ok(dbhip_copy_if_lt_dense_i32(src.get(), n, filter_value, out.get(), out_size.get(), ws.get(), ws_bytes,
                                        nullptr), "dbhip_copy_if_lt_dense_i32");
@@ -236,7 +236,7 @@ void run_scan(const char *who, size_t n, Meter &meter) {
     result->kernel_time = ev.elapsed();
     result->bytes = n * sizeof(int32_t) + count * sizeof(int32_t);
     check_status(ws.get(), who);
-    dense = n && count > n / 20;
+    dense = n && count > n / 40 * 3;
     if (inject_fault() && count) poke_xor(out.get() + count / 2, 1u);
     bool ok;
     if (host_check) {

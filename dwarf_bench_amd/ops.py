@@ -92,9 +92,11 @@ class CopyIfLt:
         self._seen: dict[int, float] = {}
         self._last_filter = None
 
-    # selectivity from which the single-launch dense variant is the faster one.  2^28 rows, same box (tools/ab.py scan):
-    # s = 2.5 % two-launch 220 / dense 240 us, 5 % 242 / 240, 7.5 % 255 / 241, 10 % 265 / 242 — the two cross at about 4.5 %
-    DENSE_ABOVE = 0.05
+    # selectivity from which the single-launch dense variant is the faster one.  2^28 rows (tools/ab.py scan), two runs:
+    # s = 2.5 % two-launch 220 / dense 240 us, 5 % 242 / 240 and 218 / 242, 7.5 % 255 / 241, 10 % 265 / 242 and 241 / 246,
+    # 25 % 328 / 258 and 312 / 260 — the dense variant is the same from run to run, the two-launch one is not (its staging
+    # traffic), and they cross somewhere between 5 % and 10 %
+    DENSE_ABOVE = 0.075
 
     def launch(self, src: torch.Tensor, filter_value: int, dense: bool | None = None) -> None:
         """Asynchronous on the current stream; nothing is read back.  dense: True / False pick the variant
