@@ -29,3 +29,18 @@ done
   echo "# built with hipcc --offload-arch=gfx950 -O3), run on the GPU box by tools/profile_round.sh"
   echo "## tools/ubench"; ./tools/ubench; echo "## tools/ubench_lds"; ./tools/ubench_lds; } > "profiles/${tag}_ubench.txt" 2>&1
 cp "profiles/${tag}_ubench.txt" "$out/"
+# BASELINE config 5 on the one GPU of the box (the same three runs as tests/test_gpu_cli.py::
+# test_partitioned_join_baseline_config_5, three iterations each): eight virtual ranks, the direct one-GPU join, and all
+# pairs through the rank's own RCCL send/recv group
+cli="dwarf_bench_amd/_lib/dwarf_bench"
+run_pjoin() {  # <name> <gpus> [ENV=VALUE]
+  local name="$1" gpus="$2" extra="${3:-DBENCH_UNUSED=1}"
+  { echo "# git head $head, tag $tag; command: $extra DWARF_BENCH_VALIDATE_MAX=1 $cli PartitionedJoinHip --device=hip --gpus $gpus --iterations 3 --input_size 1073741824"
+    env "$extra" DWARF_BENCH_VALIDATE_MAX=1 "$cli" PartitionedJoinHip --device=hip --gpus "$gpus" --iterations 3 --input_size 1073741824; } \
+    > "profiles/${tag}_pjoin_2p30_${name}.txt" 2>&1
+  cp "profiles/${tag}_pjoin_2p30_${name}.txt" "$out/"
+}
+run_pjoin 8_virtual_ranks 8
+run_pjoin direct_one_gpu 1 DWARF_BENCH_PJOIN_DIRECT=1
+run_pjoin rccl_self_exchange 1
+echo "[profile] partitioned join logs done"
