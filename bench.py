@@ -554,6 +554,9 @@ def pjoin_section(args, dist, rank, world, local, barrier, out):
         if os.environ.get("DBENCH_TEST_CHILD_FAULT"):  # test hook: the child of rank 0 dies like a process with a GPU fault
             import signal
             os.kill(os.getpid(), signal.SIGSEGV)
+    if getattr(args, "pjoin_child", False) and os.environ.get("DBENCH_TEST_CHILD_HANG"):
+        dog.leg = "test hook: a leg that never returns"  # every rank's child hangs like a collective that never completes
+        time.sleep(10 ** 6)
     if os.environ.get("DBENCH_BACKEND", "nccl") == "nccl":  # the C++ engine talks RCCL: needs one GPU per rank
         try:
             dog.leg = "C++ engine, all ranks"
@@ -605,6 +608,7 @@ def run_pjoin_children(args, rank):
         if isinstance(got, dict) and "pjoin" in got:
             if proc.returncode != 0:
                 got["pjoin"].setdefault("error", f"child exit code {proc.returncode}")
+                got["pjoin"]["child_exit_code"] = proc.returncode  # 3 = the child's watchdog cut a hung leg
             return got["pjoin"]
     return {"error": f"the partitioned-join child of rank 0 ended with exit code {proc.returncode} and no result line"}
 

@@ -181,6 +181,9 @@ struct Engine::Impl {
   // matrix to n and the column sums (what the ranks receive) to n as well.  A damaged gather (first contact with a
   // real multi-GPU ncclAllGather) stops here with a message instead of scribbling over device memory.
   void validate_matrix(const Rank &k, unsigned rel) const {
+    // test hook: what a damaged gather would look like (one cell of the last local rank's matrix off by one)
+    static const bool corrupt = [] { const char *e = std::getenv("DWARF_BENCH_PJOIN_CORRUPT_MATRIX"); return e && e[0] == '1'; }();
+    if (corrupt && planned && &k == ranks.back().get()) k.mat_host[static_cast<size_t>(rel) * P * P] += 1;
     const size_t per = n / P;
     uint64_t all = 0, cols = 0;
     for (unsigned q = 0; q < P; ++q) {

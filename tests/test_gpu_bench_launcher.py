@@ -37,3 +37,18 @@ def test_two_ranks_one_line(fault):
         assert "error" in pj and "exit code" in pj["error"], pj
     else:
         assert "error" not in pj, pj
+
+
+def test_a_hung_leg_costs_an_error_entry_and_a_nonzero_child_exit():
+    """A multi-GPU leg that never returns (an RCCL collective that hangs cannot be interrupted from Python): every
+    child's watchdog prints what has been measured so far and leaves with exit code 3 — a hung process that touched the
+    GPU is a failure, not a success — and rank 0 still prints ONE contract line, with the torch.distributed leg's
+    numbers and `pjoin.error` naming the leg."""
+    r, lines = _launch(29621, {"DBENCH_TEST_CHILD_HANG": "1", "DBENCH_PJOIN_DEADLINE_S": "25"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    pj = d["pjoin"]
+    assert "watchdog" in pj.get("error", "") and "never returns" in pj["error"] and pj.get("child_exit_code") == 3, pj
+    assert pj["torch_distributed_host"]["ms_per_step"] > 0

@@ -208,6 +208,23 @@ def test_partitioned_join_fault_injection(gpus, env):
     assert r.returncode == 0 and "ncorrect results" not in r.stderr, r.stderr
 
 
+@pytest.mark.parametrize("gpus", ["1", "3"])
+def test_partitioned_join_refuses_a_damaged_count_matrix(gpus):
+    """The gathered P x P count matrix decides every address and length of the exchange.  Before anything is queued the
+    engine checks it against what the host knows without it (row q sums to rank q's shard size): with one cell off by
+    one (DWARF_BENCH_PJOIN_CORRUPT_MATRIX=1, from the first timed step on) the step throws, the CLI reports the
+    exception like the reference's main does (main.cpp:97-100: message on stderr, exit code 0) and nothing is written
+    through a wrong offset — the next, clean run of the same shape is valid."""
+    import os
+    args = ["PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "2", "--input_size", "300007"]
+    r = _run(args, env={**os.environ, "DWARF_BENCH_PJOIN_CORRUPT_MATRIX": "1"})
+    assert r.returncode == 0, r.stderr
+    assert "Caught exception" in r.stderr and "gathered a count matrix whose row" in r.stderr, r.stderr
+    assert r.stdout.count("Host duration:") == 0
+    r = _run(args)
+    assert r.returncode == 0 and "Caught exception" not in r.stderr and "ncorrect results" not in r.stderr, r.stderr
+
+
 def test_partitioned_join_above_the_host_check_limit():
     """2^24 rows over 8 ranks sharing the GPU with the host-side check switched off: Result::valid rests on the
     device-side checks alone (what a 2^30-row run relies on)"""
