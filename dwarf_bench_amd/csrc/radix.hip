@@ -31,8 +31,7 @@
 //     coalesced global atomics per workgroup), one single-workgroup kernel per pass turns the matrix into offsets.  No
 //     rs_chunk_hist after the first pass (7 x 12 us saved) — and 367.6 us: the counting costs the scatter 6 us per pass
 //     (27.5 -> 35.6 us; counting in the write-out loop, where a wave holds one digit's run and 64 lanes hit 16 counters:
-//     40 us), the offsets kernel takes 7.9 us of which 4.5 are the write-back of what the scatter left dirty in the L2s
-//     (a kernel that reads one word and returns takes 4.8 us behind a scatter).  With 8-bit digits the table would have
+//     40 us), the offsets kernel takes 7.9 us — a kernel that reads one word and returns takes 4.8 us behind a scatter.  With 8-bit digits the table would have
 //     2 x 256 x 256 counters per chunk and about one key per counter: no aggregation, one global atomic per key.
 //   * an up-front read that only counts digit 0 per chunk and ORs the keys (a pass is skipped iff none of its digit's bits
 //     varies; every kernel derives skip flags and ping-pong parity from that word, no plan kernel), digit totals from the
@@ -44,6 +43,9 @@
 //     loads) 2.3 us; the rest is the 256-entry scan.  At best 5 us for the whole sort: not pursued.  Two lessons kept: 512-1024 workgroups ending with two atomics on the SAME word are served one per ~11 ns
 //     (the kernel then takes 34 us instead of 14), and a divide that consumes a loaded offset in the prologue puts that
 //     load's latency in front of the tile's key loads.
+//   * the scatter's stores as write-through (sc1) or non-temporal stores, so that the histogram kernel behind it would not
+//     wait for dirty L2 lines: scatter 28.4 -> 37.6 / 35.3 us (8-bit), the histogram 13.0 -> 13.0 / 16.6 us — the ~4.8 us
+//     that any kernel takes behind a scatter, however little it does, are not an L2 write-back.  199 -> 235 / 239 us.
 // A single-pass Onesweep was re-examined on paper and not built: a dependent global round trip costs 2-4 us under load
 // on this chip (dense scan) against 7 us that a workgroup spends on an 8192-key tile, and when all chunks of
 // a pass are in flight at once (2^24 keys = 512 workgroups x 32768 keys) a look-back has nothing finished to look back on.
