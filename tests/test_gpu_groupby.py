@@ -39,11 +39,17 @@ def test_wraparound_sums():
 
 @pytest.mark.parametrize("groups", [32769, 65535, 65536, 65537, 131072 + 5, 300001])
 @pytest.mark.parametrize("vals_kind", ["reference", "carry_often", "full_range", "all_ones_16", "skew_one_pair"])
-def test_packed_table_two_groups_per_lds_word(groups, vals_kind):
-    """More than 32768 groups: two 16-bit partial sums per LDS word, carries (out of the low half, out of bit 31) and value
-    bits above 16 go to the spill table.  Value ranges that never, sometimes and always carry; group counts at the table
-    boundaries, odd, and over several key ranges; uint32 wrap-around exact against expected_GroupBy restated."""
+def test_more_than_32768_groups_whatever_the_values(groups, vals_kind):
+    """More than 32768 groups: the kernel chooses between two 16-bit partial sums per LDS word (every row read once) and
+    key ranges of 32-bit sums (every row read per range) from a sample of the columns.  Value ranges that never, sometimes
+    and always carry, wide values, every row on one word's two groups; group counts at the table boundaries, odd, and
+    over several key ranges; uint32 wrap-around exact against expected_GroupBy restated."""
     n = 400003
+    keys, vals = _big_group_case(n, groups, vals_kind)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
+def _big_group_case(n, groups, vals_kind):
     keys = po.gen_uniform_u32(n, 21, 0, groups - 1)
     if vals_kind == "reference":
         vals = po.gen_uniform_u32(n, 22, 1, 10000)
@@ -56,7 +62,65 @@ def test_packed_table_two_groups_per_lds_word(groups, vals_kind):
     else:  # every row on one word's two groups: both halves carry all the time, and into each other
         keys = (np.arange(n, dtype=np.uint32) & 1) + np.uint32(groups - 2 - (groups & 1))
         vals = po.gen_uniform_u32(n, 22, 0xFF00, 0x1FFFF)
-    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+    return keys, vals
+
+
+@pytest.mark.parametrize("mode", ["force", "0"])
+def test_both_large_table_modes_on_every_input(mode):
+    """DBHIP_GB_PACKED=force / 0 pins the packed / the wide mode (a fresh process: the library reads the variable once):
+    the packed table with its LDS carry counters (two 4-bit counters per word, saturating) and its global spill path is
+    exact on inputs its own sample would never have chosen it for — wide values, values that carry on most rows, every
+    row on one word, ONE private table for all rows (executors = 1: dozens of carries per group, saturated counters) —
+    and the wide mode on the ones that would have been packed."""
+    import os, subprocess, sys
+    prog = (
+        "import numpy as np, torch\n"
+        "from dwarf_bench_amd import ops\n"
+        "from oracle import pyoracle as po\n"
+        "from tests.test_gpu_groupby import _big_group_case\n"
+        "def dev(a): return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()\n"
+        "n = 400003\n"
+        "for groups in (32776, 65536, 65537, 200001):\n"
+        "    for kind in ('reference', 'carry_often', 'full_range', 'all_ones_16', 'skew_one_pair'):\n"
+        "        k, v = _big_group_case(n, groups, kind)\n"
+        "        for executors in (0, 1, 3):\n"
+        "            plan = ops.GroupBySum(n, groups)\n"
+        "            plan.partial(dev(k), dev(v), executors); plan.merge(executors)\n"
+        "            got = plan.result().cpu().numpy().view(np.uint32)\n"
+        "            assert np.array_equal(got, po.groupby_sum(k, v, groups)), (groups, kind, executors)\n"
+        "print('both modes: ok')\n")
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "DBHIP_GB_PACKED": mode}, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0 and "both modes: ok" in r.stdout, (mode, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_the_mode_choice_avoids_the_packed_tables_cliffs():
+    """What the sample-based choice is for: the packed table is the faster one at BASELINE's configuration (2^26 rows,
+    2^16 groups, values in [1, 10000]) and would be 3.5x - 36x slower than the wide mode on full-range values, values up
+    to 60000 at 2^26 rows without its LDS carry counters, or keys clustered in the input.  Timing-free check of the
+    decision itself through the header word the kernel writes: mode 1 = packed, 2 = wide."""
+    from dwarf_bench_amd import ops
+    n, groups = 1 << 25, 65536
+    keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+
+    def mode_of(k, v):
+        plan = ops.GroupBySum(n, groups)
+        plan.launch(k, v)
+        plan.result()
+        return int(plan.ws[4:8].view(torch.int32).item())
+
+    assert mode_of(keys, ops.gen_uniform_u32(n, 43, 1, 10000)) == 1
+    assert mode_of(keys, ops.gen_uniform_u32(n, 43, 0, 2**32 - 1)) == 2          # wide values
+    assert mode_of(torch.sort(keys).values, ops.gen_uniform_u32(n, 43, 1, 10000)) == 2  # clustered keys: hot in every window
+    hot = keys.clone()
+    hot[::50] = 7                                                                  # one key with 2 % of the rows
+    assert mode_of(hot, ops.gen_uniform_u32(n, 43, 1, 10000)) == 2
+    assert mode_of(keys, ops.gen_uniform_u32(n, 43, 1, 60000)) == 2                # sums that would carry on most groups
+    small = ops.gen_uniform_u32(1 << 22, 42, 0, groups - 1)                        # too short for the packed table to pay
+    plan = ops.GroupBySum(1 << 22, groups)
+    plan.launch(small, ops.gen_uniform_u32(1 << 22, 43, 1, 10000))
+    plan.result()
+    assert int(plan.ws[4:8].view(torch.int32).item()) == 2
 
 
 def test_skewed_keys():

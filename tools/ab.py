@@ -8,6 +8,9 @@ the contract numbers come from bench.py.
   sort [lg]       2^lg-key sort, 8- and 4-bit digits (drop-max-mean of 9, refresh copy subtracted); default lg 24
   sort-only       three 2^24 sorts and nothing else (counter collection; SORT_BITS=4|8)
   groupby         2^26 rows at 2^16 / 2^15 / 2^10 / 64 groups (drop-max-mean of 9)
+  groupby-shapes  more than 32768 groups over row counts, group counts and value ranges (median of 5): run it with
+                  DBHIP_GB_PACKED=0 beside the default to see what the kernel's choice between its two large-table modes
+                  buys and that it costs nothing where the packed table would be slow
   join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
   partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
   reduce          2^28-row reduce (median of 15; DBHIP_RED_WGS)
@@ -112,6 +115,22 @@ def groupby(_):
         ok = bool(torch.equal(u64(plan.result()), ref & 0xFFFFFFFF))
         res.append(f"G={groups}: {t:6.1f} us {'ok' if ok else 'WRONG'}")
     print(f"{TAG:16s} " + "  ".join(res), flush=True)
+
+
+def groupby_shapes(_):
+    tag = "packed=" + os.environ.get("DBHIP_GB_PACKED", "auto")
+    for lg, groups, hi in ((26, 65536, 10000), (27, 65536, 10000), (28, 65536, 10000), (26, 65536, 60000),
+                           (26, 65536, 2**32 - 1), (26, 1 << 18, 10000), (27, 1 << 17, 10000), (24, 65536, 10000)):
+        n = 1 << lg
+        keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+        vals = ops.gen_uniform_u32(n, 43, 1, hi)
+        plan = ops.GroupBySum(n, groups)
+        t = median(times(lambda: plan.launch(keys, vals), 5))
+        ref = torch.zeros(groups, dtype=torch.int64, device="cuda").index_add_(0, keys.to(torch.int64), vals.to(torch.int64))
+        ok = bool(torch.equal(u64(plan.result()), ref & 0xFFFFFFFF))
+        mode = int(plan.ws[4:8].view(torch.int32).item())
+        print(f"{tag:12s} n=2^{lg} G={groups} vals<={hi}: {t:8.1f} us  mode {('-', 'packed', 'wide')[mode]}  {'ok' if ok else 'WRONG'}", flush=True)
+        del keys, vals, plan
 
 
 def join(lg):
@@ -263,7 +282,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "join": join, "partition": partition,
+MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "join": join, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
