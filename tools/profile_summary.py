@@ -29,7 +29,7 @@ DWARFS = {
     "scan": (r"scan_chunk_kernel|scan_move_kernel", r"scan_chunk_kernel", True),
     "sort_8bit": (r"rs_\w+<8", r"rs_histogram", True),
     "sort_4bit": (r"rs_\w+<4", r"rs_histogram", True),
-    "groupby": (r"gb_aggregate_kernel|gb_reduce\w*kernel", r"gb_aggregate_kernel", True),
+    "groupby": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", True),
     # join: 4-B/lane reads and random 16-B gathers — widths the guide calls uncalibrated: raw counter, not doubled
     "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_build_kernel<false>", False),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", False),
@@ -60,7 +60,7 @@ CONFIGS = {
     "scan_2p28": (r"scan_chunk_kernel|scan_move_kernel", r"scan_chunk_kernel", r"scan_move_kernel"),
     "sort_2p24_8bit": (r"rs_\w+<8|rs_finalize", r"rs_histogram_kernel<8", r"rs_finalize_kernel"),
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
-    "groupby_2p26_2p16": (r"gb_aggregate_kernel|gb_reduce\w*kernel", r"gb_aggregate_kernel", r"gb_reduce\w*kernel"),
+    "groupby_2p26_2p16": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", r"gb_reduce\w*kernel"),
     "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_build_kernel<false>"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
     # the radix join: both sides through the partitioner, then the fused build + probe launch
