@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256) void scan_move_kernel(const int *__restrict__ 
 //   ... 256 granules per poll                                                   342 / 274 us
 //   (round 3, this kernel) next ticket taken right after the hand-off, before   s = 0.1: 260 us against 246, 0.5: 321
 //   the emission, instead of at the top of the next chunk                       against 297 — the same stall, shorter
+//   (round 3, this kernel) the four counted rows simply KEPT in their            s = 0.1: 243 against 247.5, 0.5: 311 against
+//   registers (no second read at all: the registers are reloaded anyway)        299, 1.0: 378 against 373 — the second read is
+//                                                                               not what the kernel waits for, and having it
+//                                                                               in flight helps the emission-heavy cases
 //   one granule per line: 16- / 8- (this kernel) / 4-wave workgroups            316-318 / 250, 300 / 239, 334 / 320 us
 // Slower than the two-launch path for sparse predicates (hand-off per chunk, a quarter of the input read twice):
 // callers choose — ops.CopyIfLt and the TwoPassScan dwarf switch on the selectivity of the previous call (> 0.1).
