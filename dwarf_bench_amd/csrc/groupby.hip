@@ -49,6 +49,10 @@ constexpr int kGbMaxLdsGroups = 32768;  // 128 KiB table of 32-bit sums
 constexpr int kGbMaxPackedGroups = 2 * kGbMaxLdsGroups;  // the same 128 KiB with two 16-bit partial sums per word
 constexpr int kGbCarryWords = kGbMaxLdsGroups / 4;       // one byte of carry counters per table word: 32 KiB
 constexpr int kGbBigThreads = 1024;     // one workgroup per CU when the table is large
+#ifndef DBHIP_GB_CROWD
+#define DBHIP_GB_CROWD 24
+#endif
+constexpr int kGbCrowd = DBHIP_GB_CROWD;  // lanes of a wave on one group from which they are summed before the LDS add
 #ifndef DBHIP_GB_VEC
 #define DBHIP_GB_VEC 2
 #endif
@@ -213,6 +217,14 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
       if (k16 || k32 || (val >> 16)) gb_spill_global(spill, groups, key, val & 0xFFFF0000u, k32, k16);
     }
   };
+  // Rows of ONE group in many lanes of a wave (a hot key, keys that come in runs, sorted keys): the LDS serves the lanes of
+  // an atomic that meet on one word one after the other.  Up to 16 lanes per word that hides behind the HBM reads (one key
+  // in all 2^26 rows, 4096 groups in 4 lane copies: 97 us against 94 for uniform keys), 32 and 64 do not (16384 and 32768
+  // groups, one copy: 244-251 us against 100-107; 65536 groups 471 against 111).  So where the table has fewer than four
+  // lane copies every row of keys asks how many lanes share the first lane's group, and kGbCrowd or more are summed
+  // across the wave and added once (one key in all rows: 107-114 us; the test on uniform keys: nothing measurable; with
+  // the test on tables of 16 copies, or crowds from 8 lanes: 92 -> 104 us, the wave sum costs more than the queue).
+  const bool crowd_guard = !PACKED && geo.replicas <= 2;
   auto add_step = [&](size_t base, const u32x4 (&k)[kGbVecPerIter], const u32x4 (&v)[kGbVecPerIter]) {
 #pragma unroll
     for (int u = 0; u < kGbVecPerIter; ++u) {
@@ -222,12 +234,25 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned rel = kk[c] - lo;
+        bad_key |= live && kk[c] >= groups;
         if (PACKED) {
           if (rel < span) add_packed(kk[c], rel, vv[c]);
-        } else if (rel < span) {
-          atomicAdd(&s_table[rep_off + rel], vv[c]);
+          continue;
         }
-        bad_key |= live && kk[c] >= groups;
+        const bool in = rel < span;
+        if (crowd_guard) {  // (uniform; every lane of the wave is here: the loop around add_step is uniform)
+          const unsigned long long act = __ballot(in);
+          const unsigned first = __builtin_amdgcn_readlane(rel, act ? __builtin_ctzll(act) : 0);
+          const bool same = in && rel == first;
+          const unsigned long long crowd = __ballot(same);
+          if (__builtin_popcountll(crowd) >= kGbCrowd) {
+            const unsigned sum = wave_reduce_add(same ? vv[c] : 0u);
+            if ((tid & (kWave - 1)) == static_cast<unsigned>(__builtin_ctzll(crowd))) atomicAdd(&s_table[rep_off + first], sum);
+            if (in && !same) atomicAdd(&s_table[rep_off + rel], vv[c]);
+            continue;
+          }
+        }
+        if (in) atomicAdd(&s_table[rep_off + rel], vv[c]);
       }
     }
   };

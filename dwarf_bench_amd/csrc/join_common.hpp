@@ -58,9 +58,30 @@ inline bool jl_use_ujoin(size_t n_build) {
 #ifndef DBHIP_JL_K2_BIAS
 #define DBHIP_JL_K2_BIAS 0
 #endif
+// A GIANT partition: one hot key (or a few) gives a partition far more rows than one workgroup should walk alone —
+// every other row of 2^24 carrying one key made the build 22.5 ms against 0.3 ms.  A partition above jl_giant_rows(n)
+// rows is left out by the per-partition build and counted / filled by all workgroups together, slice by slice
+// (jl_giant_count / jl_giant_fill in join_lds.hip).  There are fewer than n / jl_giant_rows(n) of them: the scratch
+// below (list, finished-slice counters, per giant the key counts and the id cursors of its sub-table's slots) is sized
+// for that, so no giant is ever left to the slow path.  Below 2^18 build rows the two extra launches would cost more
+// than a giant can (a partition of 2^17 rows: 0.3 ms): the path is off, jl_max_giants = 0.
+__host__ __device__ __forceinline__ size_t jl_giant_rows(size_t n) {
+  const size_t t = n / 1024;
+  return t < 32768 ? static_cast<size_t>(32768) : t;
+}
+inline unsigned jl_max_giants(size_t n) {
+  return n < (static_cast<size_t>(1) << 18) ? 0u : static_cast<unsigned>(n / jl_giant_rows(n) + 1);
+}
+// scratch: count, pad[3] | part[max] | done[max] | counts[max][kJlSubSlots] | cursors[max][kJlSubSlots]; the first
+// jl_giant_header_bytes are cleared with the partitioner's meta words, a giant's counts by the workgroup that lists it
+inline size_t jl_giant_header_bytes(unsigned max_giants) { return max_giants ? 16 + 8 * static_cast<size_t>(max_giants) : 0; }
+inline size_t jl_giant_bytes(unsigned max_giants) {
+  return max_giants ? align_up(jl_giant_header_bytes(max_giants), 16) + static_cast<size_t>(max_giants) * kJlSubSlots * 8 : 0;
+}
+
 struct JlLayout {
-  unsigned parts, k1, k2, log2_k2;
-  size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, total;
+  unsigned parts, k1, k2, log2_k2, max_giants;
+  size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, giant_off, total;
 };
 
 inline JlLayout jl_layout(size_t n) {
@@ -84,7 +105,9 @@ inline JlLayout jl_layout(size_t n) {
   L.rids_b_off = L.keys_b_off + (L.k2 > 1 ? col : 0);
   L.meta_off = L.rids_b_off + (L.k2 > 1 ? col : 0);
   L.meta_bytes = sizeof(unsigned long long) * ((2 * 64 + 2) * static_cast<size_t>(L.k1) + 2 + 3 * static_cast<size_t>(L.parts) + 1);  // 64 = kJlGroups
-  L.total = align_up(L.meta_off + L.meta_bytes, kWsAlign);
+  L.max_giants = jl_max_giants(n);
+  L.giant_off = align_up(L.meta_off + L.meta_bytes, kWsAlign);
+  L.total = align_up(L.giant_off + jl_giant_bytes(L.max_giants), kWsAlign);
   return L;
 }
 

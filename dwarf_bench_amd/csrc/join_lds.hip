@@ -678,6 +678,19 @@ struct JlMatchArgs {
   const unsigned long long *sstarts; // parts + 1 offsets
   unsigned *out_rid, *out_pos, *out_cnt;
 };
+// The giant partitions' scratch (join_common.hpp: jl_giant_bytes): max == 0 switches the path off.
+struct JlGiants {
+  unsigned *base;           // count, pad[3] | part[max] | done[max] | counts[max][kJlSubSlots] | cursors[max][kJlSubSlots]
+  unsigned max;
+  unsigned long long rows;  // a partition with more rows than this is a giant
+  __host__ __device__ unsigned *count() const { return base; }
+  __host__ __device__ unsigned *part() const { return base + 4; }
+  __host__ __device__ unsigned *done() const { return base + 4 + max; }
+  __host__ __device__ unsigned *counts(unsigned g) const {
+    return base + ((4 + 2 * static_cast<size_t>(max) + 3) & ~static_cast<size_t>(3)) + static_cast<size_t>(g) * kJlSubSlots;
+  }
+  __host__ __device__ unsigned *cursors(unsigned g) const { return counts(max) + static_cast<size_t>(g) * kJlSubSlots; }
+};
 template <bool kMatch>
 __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
@@ -685,7 +698,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
                                                                    u32x2 *__restrict__ table, unsigned parts,
                                                                    unsigned n_rows, unsigned pos_bits,
                                                                    unsigned *__restrict__ ids, unsigned *status,
-                                                                   JlMatchArgs match) {
+                                                                   JlMatchArgs match, JlGiants giants) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
   unsigned *lk = s_lds;                // keys
   unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
@@ -719,6 +732,20 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     asm volatile("v_mov_b32 %0, %0" : "+v"(carry[r].y));
   }
   while (true) {
+    if (!kMatch && giants.max != 0 && hi - lo > giants.rows) {  // (uniform over the workgroup)
+      // a giant partition (join_common.hpp): listed for jl_giant_count / jl_giant_fill, which all workgroups share, and
+      // published here as an EMPTY sub-table — that is the state their claims of its slots start from
+      if (tid == 0) s_end = atomicAdd(giants.count(), 1u);
+      JL_BUILD_BARRIER();
+      const unsigned slot = s_end;
+      JL_BUILD_BARRIER();  // (s_end is written again below)
+      if (slot < giants.max) {  // always: fewer than n / giants.rows partitions can be this large
+        if (tid == 0) giants.part()[slot] = static_cast<unsigned>(part);
+        unsigned *gc = giants.counts(slot);
+        for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) gc[i] = 0;
+        hi = lo;
+      }
+    }
     for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
       lk[i] = kEmptyKey;
       lc[i] = 0;
@@ -939,6 +966,245 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     hi = nhi;
 #pragma unroll
     for (int r = 0; r < kJlPre; ++r) carry[r] = nxt[r];
+  }
+}
+
+// ---- giant partitions: all workgroups together, slice by slice ----------------------------------------------------
+// jl_build_kernel leaves a partition above giants.rows rows out (an empty sub-table in its place) and lists it.  Such a
+// partition is a few hot keys — any number of rows, still at most kJlSubSlots distinct keys — and one workgroup walks
+// 0.38 G rows/s.  Two launches over slices of kJlSlice rows of the listed partitions:
+//   jl_giant_count  a slice's rows are counted per key in an LDS sub-table (as the build does); every distinct key of the
+//                   slice then claims its slot of the partition's sub-table IN HBM (atomicCAS on the empty slots the build
+//                   published; same home slot, same linear probing: the probe kernel reads it like any other sub-table)
+//                   and adds the slice's count to that slot's counter — one memory-side atomic per slice and key, not per
+//                   row.  The workgroup that finishes a giant's LAST slice (a counter per giant) scans the slot counters:
+//                   first id position of every slot -> the table's position words and the slot cursors.
+//   jl_giant_fill   the slices are counted again the same way; per distinct key ONE returning add on the slot's cursor
+//                   reserves the slice's share of the key's id range, then every row takes its place inside the share
+//                   from an LDS cursor and stores its row id.
+// Lanes of a wave that meet on one LDS counter (that is what a hot key is) are added by one lane: jl_take.
+// Nothing here waits for another workgroup.
+constexpr unsigned kJlSlice = 8192;        // rows of a slice: 16 per thread
+constexpr int kJlGiantThreads = 512;
+constexpr unsigned kJlCrowd = 16;          // lanes on one counter from which one of them adds for all
+
+// every live lane takes the next value of counter cnt[s] (returns it; cnt[s] += number of live lanes on s)
+__device__ __forceinline__ unsigned jl_take(unsigned *cnt, unsigned s, bool live) {
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const unsigned long long act = __ballot(live);
+  if (act == 0) return 0u;  // (uniform)
+  const unsigned first = __builtin_amdgcn_readlane(s, __builtin_ctzll(act));
+  const bool same = live && s == first;
+  const unsigned long long crowd = __ballot(same);
+  const unsigned c = static_cast<unsigned>(__builtin_popcountll(crowd));
+  if (c < kJlCrowd) return live ? atomicAdd(&cnt[s], 1u) : 0u;
+  const unsigned leader = static_cast<unsigned>(__builtin_ctzll(crowd));
+  unsigned old = 0;
+  if (lane == leader) old = atomicAdd(&cnt[first], c);
+  old = __builtin_amdgcn_readlane(old, leader);
+  if (same) return old + mbcnt(crowd);
+  return live ? atomicAdd(&cnt[s], 1u) : 0u;
+}
+
+// the slices of the listed giants as one flat list: s_first[g] = index of giant g's first slice (s_first[ng] = total)
+__device__ __forceinline__ unsigned jl_giant_slices(const JlGiants &giants, const unsigned long long *__restrict__ starts,
+                                                    unsigned *s_first, unsigned *s_wsum, unsigned *ng_out) {
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  unsigned ng = *giants.count();
+  ng = ng < giants.max ? ng : giants.max;
+  *ng_out = ng;
+  if (ng == 0) return 0u;
+  unsigned total = 0;
+  for (unsigned g0 = 0; g0 < ng; g0 += kJlGiantThreads) {  // (uniform trip count)
+    const unsigned g = g0 + tid;
+    unsigned mine = 0;
+    if (g < ng) {
+      const unsigned p = giants.part()[g];
+      mine = static_cast<unsigned>((starts[p + 1] - starts[p] + kJlSlice - 1) / kJlSlice);
+    }
+    const unsigned incl = wave_inclusive_scan(mine);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned before = total;
+    for (unsigned w = 0; w < wave; ++w) before += s_wsum[w];
+    if (g < ng) s_first[g] = before + incl - mine;
+    for (unsigned w = 0; w < kJlGiantThreads / kWave; ++w) total += s_wsum[w];
+    __syncthreads();
+  }
+  if (tid == 0) s_first[ng] = total;
+  __syncthreads();
+  return total;
+}
+// giant of flat slice `item` (largest g with s_first[g] <= item)
+__device__ __forceinline__ unsigned jl_giant_of(const unsigned *s_first, unsigned ng, unsigned item) {
+  unsigned lo = 0, hi = ng;
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) / 2;
+    if (s_first[mid] <= item) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// count the rows [a, b) per key in the LDS sub-table lk / lc (cleared here)
+__device__ __forceinline__ void jl_slice_count(const u32x2 *__restrict__ rows, size_t a, size_t b, unsigned *lk, unsigned *lc,
+                                               unsigned *status) {
+  const unsigned tid = threadIdx.x;
+  for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
+    lk[i] = kEmptyKey;
+    lc[i] = 0;
+  }
+  __syncthreads();
+  for (size_t i0 = a; i0 < b; i0 += 4 * static_cast<size_t>(kJlGiantThreads)) {  // (uniform) four rows per lane in flight
+    u32x2 r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t i = i0 + static_cast<size_t>(q) * kJlGiantThreads + tid;
+      r[q] = i < b ? rows[i] : u32x2{kEmptyKey, 0u};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool have = i0 + static_cast<size_t>(q) * kJlGiantThreads + tid < b;
+      const unsigned sl = have ? jl_claim(lk, r[q].x, status) : kJlSubSlots;
+      (void)jl_take(lc, sl < kJlSubSlots ? sl : 0u, sl < kJlSubSlots);
+    }
+  }
+  __syncthreads();
+}
+// slot of `key` in the giant's sub-table in HBM; claim = true: take the first empty slot of its chain if it is not there
+// yet.  kJlSubSlots: the sub-table is full of other keys (flagged) / the key is not there.
+__device__ __forceinline__ unsigned jl_giant_slot(u32x2 *sub, unsigned key, bool claim, unsigned *status) {
+  unsigned s = jl_home_slot(fmix32(key));
+  for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
+    unsigned *kw = reinterpret_cast<unsigned *>(sub + s);
+    unsigned k = __builtin_nontemporal_load(kw);
+    if (k == kEmptyKey) {
+      if (!claim) return kJlSubSlots;
+      k = atomicCAS(kw, kEmptyKey, key);
+      if (k == kEmptyKey) return s;
+    }
+    if (k == key) return s;
+    s = jl_next_slot(s);
+  }
+  if (claim) atomicOr(status, DBHIP_DEV_TABLE_FULL);
+  return kJlSubSlots;
+}
+
+__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u32x2 *__restrict__ rows,
+                                                                         const unsigned long long *__restrict__ starts,
+                                                                         u32x2 *table, unsigned pos_bits, JlGiants giants,
+                                                                         unsigned *status) {
+  __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
+  __shared__ unsigned s_first[1026], s_wsum[kJlGiantThreads / kWave], s_last;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  unsigned ng;
+  const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    const unsigned g = jl_giant_of(s_first, ng, item);
+    const unsigned part = giants.part()[g];
+    const size_t lo = starts[part], hi = starts[part + 1];
+    const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
+    const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
+    jl_slice_count(rows, a, b, lk, lc, status);
+    u32x2 *sub = table + static_cast<size_t>(part) * kJlSubSlots;
+    unsigned *gcount = giants.counts(g);
+    for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
+      const unsigned c = lc[i];
+      if (c) {
+        const unsigned gs = jl_giant_slot(sub, lk[i], true, status);
+        if (gs < kJlSubSlots) atomicAdd(&gcount[gs], c);
+      }
+    }
+    // the last slice of a giant to get here turns the slot counters into positions (every add above is performed before
+    // this workgroup's tick on the giant's counter: fence, barrier, then the tick)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&giants.done()[g], 1u) + 1u == s_first[g + 1] - s_first[g] ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {  // (uniform)
+      __threadfence();
+      constexpr unsigned kPer = kJlSubSlots / kJlGiantThreads;
+      unsigned c[kPer], mine = 0;
+#pragma unroll
+      for (unsigned j = 0; j < kPer; ++j) {
+        c[j] = atomicAdd(&gcount[tid * kPer + j], 0u);  // (a read that no stale cache line can answer)
+        mine += c[j];
+      }
+      const unsigned incl = wave_inclusive_scan(mine);
+      if (lane == kWave - 1) s_wsum[wave] = incl;
+      __syncthreads();
+      unsigned run = static_cast<unsigned>(lo) + incl - mine;
+      for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
+      const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
+      unsigned *cursor = giants.cursors(g);
+#pragma unroll
+      for (unsigned j = 0; j < kPer; ++j) {
+        const unsigned slot = tid * kPer + j;
+        unsigned f = c[j] ? c[j] - 1 : 0u;
+        f = f < cnt_esc ? f : cnt_esc;
+        cursor[slot] = run;
+        reinterpret_cast<unsigned *>(sub + slot)[1] = pos_bits < 32 ? (run | (f << pos_bits)) : run;
+        run += c[j];
+      }
+    }
+    __syncthreads();  // lk / lc / s_wsum / s_last are reused by the next slice
+  }
+}
+
+__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_fill_kernel(const u32x2 *__restrict__ rows,
+                                                                        const unsigned long long *__restrict__ starts,
+                                                                        u32x2 *table, JlGiants giants,
+                                                                        unsigned *__restrict__ ids, unsigned *status) {
+  __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
+  __shared__ unsigned s_first[1026], s_wsum[kJlGiantThreads / kWave];
+  const unsigned tid = threadIdx.x;
+  unsigned ng;
+  const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    const unsigned g = jl_giant_of(s_first, ng, item);
+    const unsigned part = giants.part()[g];
+    const size_t lo = starts[part], hi = starts[part + 1];
+    const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
+    const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
+    jl_slice_count(rows, a, b, lk, lc, status);
+    u32x2 *sub = table + static_cast<size_t>(part) * kJlSubSlots;
+    unsigned *cursor = giants.cursors(g);
+    // the slice's share of every key's id range: lc[i] becomes the first position of the share
+    for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
+      const unsigned c = lc[i];
+      if (c) {
+        const unsigned gs = jl_giant_slot(sub, lk[i], false, status);
+        lc[i] = gs < kJlSubSlots ? atomicAdd(&cursor[gs], c) : 0xFFFFFFFFu;  // (not there: only behind a full table, flagged)
+      }
+    }
+    __syncthreads();
+    for (size_t i0 = a; i0 < b; i0 += 4 * static_cast<size_t>(kJlGiantThreads)) {  // (uniform)
+      u32x2 r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t i = i0 + static_cast<size_t>(q) * kJlGiantThreads + tid;
+        r[q] = i < b ? rows[i] : u32x2{kEmptyKey, 0u};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned key = r[q].x;
+        unsigned sl = kJlSubSlots;
+        if (i0 + static_cast<size_t>(q) * kJlGiantThreads + tid < b && key != kEmptyKey) {
+          unsigned t = jl_home_slot(fmix32(key));
+          for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
+            const unsigned k = lk[t];
+            if (k == key) {
+              sl = t;
+              break;
+            }
+            if (k == kEmptyKey) break;
+            t = jl_next_slot(t);
+          }
+        }
+        const bool live = sl < kJlSubSlots;
+        const unsigned pos = jl_take(lc, live ? sl : 0u, live);
+        if (live && pos - static_cast<unsigned>(lo) < static_cast<unsigned>(hi - lo)) ids[pos] = r[q].y;  // (outside: only behind a full table)
+      }
+    }
+    __syncthreads();  // lk / lc are reused by the next slice
   }
 }
 
@@ -1256,9 +1522,26 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
+  // giant partitions (join_common.hpp): listed by the build kernel, counted and filled by two launches of their own
+  JlGiants giants{nullptr, 0u, ~0ull};
+  static const bool no_giants = [] { const char *v = getenv("DBHIP_JL_NO_GIANTS"); return v && v[0] == '1'; }();  // A/B knob
+  if (L.max_giants && !no_giants) {
+    giants.base = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + L.giant_off);
+    giants.max = L.max_giants;
+    giants.rows = jl_giant_rows(n);
+    const hipError_t eg = fill_async(giants.base, 0, jl_giant_header_bytes(L.max_giants), s);
+    if (eg != hipSuccess) return static_cast<int>(eg);
+  }
   hipLaunchKernelGGL(jl_build_kernel<false>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, p.keys,
                      p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
-                     JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr});
+                     JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, giants);
+  if (giants.max) {
+    const unsigned grid = static_cast<unsigned>(dev.cus) * (2048 / kJlGiantThreads);
+    hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
+                       p.starts, p.table, jl_pos_bits(n), giants, p.status);
+    hipLaunchKernelGGL(jl_giant_fill_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
+                       p.starts, p.table, giants, ids, p.status);
+  }
   return launch_status();
 }
 
@@ -1330,7 +1613,7 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
   hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
                      static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
                      static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, reinterpret_cast<unsigned *>(base),
-                     JlMatchArgs{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt});
+                     JlMatchArgs{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt}, JlGiants{nullptr, 0u, ~0ull});
   return launch_status();
 }
 

@@ -78,6 +78,9 @@ constexpr int kRsWaves = kRsThreads / kWave;
 #ifndef DBHIP_RS_WPE
 #define DBHIP_RS_WPE 4
 #endif
+#ifndef DBHIP_RS_CROWD_ROWS
+#define DBHIP_RS_CROWD_ROWS 2
+#endif
 constexpr int kRsKpt = DBHIP_RS_KPT;             // keys per lane per tile
 constexpr int kRsWaveKeys = kWave * kRsKpt;      // 1024 contiguous keys per wave
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;  // 8192 keys
@@ -163,6 +166,13 @@ __device__ __forceinline__ unsigned lanes_in(LaneMask m) { return __builtin_popc
 // workgroups leave CUs idle: 360 -> 377 us with 4)
 template <int BITS>
 constexpr int rs_hist_cpw() { return BITS == 8 ? 4 : 1; }
+// LDS histograms are kept in several copies, lane l adding into copy l % copies, copy c lying c words further (its
+// counter of a digit in another bank): the LDS serves the lanes of one atomic that hit the same word one after the
+// other, so keys that crowd into a few digits (two distinct values, 90 % one value, sorted input in its top pass)
+// made the histogram kernels 4.5-8 x slower than on spread keys (2^24 keys, 8-bit: 13 -> 58 us per pass, the up-front
+// read 25 -> 130-200 us).  With 4-bit digits 64 lanes share 16 counters even on uniform keys.
+template <int BITS>
+constexpr int rs_hist_copies() { return BITS == 8 ? 8 : 16; }
 
 template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned *__restrict__ keys,
@@ -177,20 +187,39 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
   // ds_add per key made this kernel 70 us at 2^24 keys against 32 us for the byte version.
   constexpr int kBins = 256, kBytes = 4;
   constexpr int kRadix = 1 << BITS;
-  __shared__ unsigned s_hist[kBytes * kBins];  // [0][*] is filled from the chunk counts
   constexpr int kCpw = rs_hist_cpw<BITS>();  // consecutive chunks whose pass-0 counts are written side by side
-  __shared__ unsigned s_chunks[kCpw][kBins];
-  for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) s_hist[i] = 0;
+  // every histogram in kCopies copies, lane l adding into copy l % kCopies (see rs_hist_copies; four here: seven
+  // byte histograms at eight copies would halve the resident workgroups of a kernel that waits for HBM)
+  constexpr int kCopies = 4, kStride = kBins + 1;
+  __shared__ unsigned s_byte0[kBins];                          // byte 0 over the workgroup's chunks (from s_chunks)
+  __shared__ unsigned s_upper[kBytes - 1][kCopies * kStride];  // bytes 1..3 over the workgroup's chunks
+  __shared__ unsigned s_chunks[kCpw][kCopies * kStride];       // byte 0 of the chunks in hand
+  for (int i = threadIdx.x; i < kBins; i += kRsThreads) s_byte0[i] = 0;
+  for (int i = threadIdx.x; i < (kBytes - 1) * kCopies * kStride; i += kRsThreads) (&s_upper[0][0])[i] = 0;
+  const unsigned my_copy = (threadIdx.x & (kCopies - 1)) * kStride;
+  auto chunk_count = [&](int cc, int d) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < kCopies; ++k) sum += s_chunks[cc][k * kStride + d];
+    return sum;
+  };
+  auto byte_total = [&](int byte, int d) {
+    if (byte == 0) return s_byte0[d];
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < kCopies; ++k) sum += s_upper[byte - 1][k * kStride + d];
+    return sum;
+  };
   const size_t chunk_keys = tiles_per_chunk * kRsTile;
   const size_t groups = (num_chunks + kCpw - 1) / kCpw;
   for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
-    for (int i = threadIdx.x; i < kCpw * kBins; i += kRsThreads) (&s_chunks[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kCpw * kCopies * kStride; i += kRsThreads) (&s_chunks[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int cc = 0; cc < kCpw; ++cc) {
       const size_t chunk = group * kCpw + cc;
       if (chunk >= num_chunks) break;
-      unsigned *s_chunk = s_chunks[cc];
+      unsigned *s_chunk = s_chunks[cc] + my_copy;
       const size_t lo = chunk * chunk_keys;
       size_t hi = lo + chunk_keys;
       hi = hi < n ? hi : n;
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
         const unsigned k[4] = {v.x ^ xor_mask, v.y ^ xor_mask, v.z ^ xor_mask, v.w ^ xor_mask};
   #pragma unroll
         for (int p = 0; p < kBytes; ++p) {
-          unsigned *hist = p == 0 ? s_chunk : s_hist + p * kBins;
+          unsigned *hist = p == 0 ? s_chunk : s_upper[p == 0 ? 0 : p - 1] + my_copy;
           // a byte that is the same in the whole wave (the upper bytes of small keys: the reference's
           // [1,10000] data) would serialise 64 same-address ds_add: one lane adds the lot instead
           const unsigned d0 = (k[0] >> (p * 8)) & (kBins - 1);
@@ -233,34 +262,46 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
         const unsigned k = keys[i] ^ xor_mask;
         atomicAdd(&s_chunk[k & (kBins - 1)], 1u);
   #pragma unroll
-        for (int p = 1; p < kBytes; ++p) atomicAdd(&s_hist[p * kBins + ((k >> (p * 8)) & (kBins - 1))], 1u);
+        for (int p = 1; p < kBytes; ++p) atomicAdd(&s_upper[p - 1][my_copy + ((k >> (p * 8)) & (kBins - 1))], 1u);
       }
     }
     __syncthreads();
     // pass 0's counts of these chunks: the byte bins themselves (side by side: one 16-byte store per digit where the
     // row allows it, see rs_chunk_hist_kernel), or (4-bit digits) their sums over the high nibble
     const size_t chunk0 = group * kCpw;
+    unsigned mine[kCpw] = {};  // thread d < 256: byte-0 bin d of each chunk in hand
+    if (threadIdx.x < kBins) {
+#pragma unroll
+      for (int cc = 0; cc < kCpw; ++cc) mine[cc] = chunk_count(cc, threadIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) {  // the summed counts back into copy 0, for the nibble sums below
+      unsigned c = 0;
+#pragma unroll
+      for (int cc = 0; cc < kCpw; ++cc) {
+        s_chunks[cc][threadIdx.x] = mine[cc];
+        c += mine[cc];
+      }
+      s_byte0[threadIdx.x] += c;
+    }
     if (BITS == 8) {
       const bool vec = kCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;
-      for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
-        unsigned *row = counts0 + static_cast<size_t>(d) * num_chunks + chunk0;
+      if (threadIdx.x < kRadix) {
+        unsigned *row = counts0 + static_cast<size_t>(threadIdx.x) * num_chunks + chunk0;
         if (vec) {
-          *reinterpret_cast<u32x4 *>(row) = u32x4{s_chunks[0][d], s_chunks[1 % kCpw][d], s_chunks[2 % kCpw][d], s_chunks[3 % kCpw][d]};
+          *reinterpret_cast<u32x4 *>(row) = u32x4{mine[0], mine[1 % kCpw], mine[2 % kCpw], mine[3 % kCpw]};
         } else {
-          for (int cc = 0; cc < kCpw && chunk0 + cc < num_chunks; ++cc) row[cc] = s_chunks[cc][d];
+          for (int cc = 0; cc < kCpw && chunk0 + cc < num_chunks; ++cc) row[cc] = mine[cc];
         }
       }
-    } else if (threadIdx.x < kRadix) {
-      unsigned c = 0;
+    } else {
+      __syncthreads();
+      if (threadIdx.x < kRadix) {
+        unsigned c = 0;
 #pragma unroll
-      for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunks[0][hi4 * 16 + threadIdx.x];
-      counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk0] = c;
-    }
-    for (int d = threadIdx.x; d < kBins; d += kRsThreads) {  // thread d owns s_hist[0][d]
-      unsigned c = 0;
-#pragma unroll
-      for (int cc = 0; cc < kCpw; ++cc) c += s_chunks[cc][d];
-      s_hist[d] += c;
+        for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunks[0][hi4 * 16 + threadIdx.x];
+        counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk0] = c;
+      }
     }
     __syncthreads();
   }
@@ -268,14 +309,14 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
   unsigned *copy = totals + static_cast<size_t>(blockIdx.x % kRsTotalCopies) * kRsMaxPasses * kRsMaxRadix;
   if (BITS == 8) {
     for (int i = threadIdx.x; i < kBytes * kBins; i += kRsThreads) {
-      const unsigned c = s_hist[i];
+      const unsigned c = byte_total(i / kBins, i % kBins);
       if (c) atomicAdd(&copy[(i / kBins) * kRsMaxRadix + (i % kBins)], c);
     }
   } else if (threadIdx.x < kBytes * 2 * kRadix) {  // 8 passes x 16 digits: pass 2q = low nibble of byte q, 2q+1 = high
     const unsigned pass = threadIdx.x / kRadix, d = threadIdx.x % kRadix, byte = pass / 2;
     unsigned c = 0;
 #pragma unroll
-    for (int o = 0; o < 16; ++o) c += s_hist[byte * kBins + ((pass & 1u) ? d * 16 + o : o * 16 + d)];
+    for (int o = 0; o < 16; ++o) c += byte_total(byte, (pass & 1u) ? d * 16 + o : o * 16 + d);
     if (c) atomicAdd(&copy[pass * kRsMaxRadix + d], c);
   }
 }
@@ -327,19 +368,23 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
   // line of its own — 512 K partial-line writes per pass at 2^24 keys, 16 MiB written back for a 2 MiB matrix.
   constexpr int kRadix = 1 << BITS;
   constexpr int kRsHistCpw = rs_hist_cpw<BITS>();
-  __shared__ unsigned s_hist[kRsHistCpw][kRadix];
+  // kCopies histograms per chunk, lane l counts in copy l % kCopies (rs_hist_copies): keys that crowd into a few
+  // digits no longer queue on one LDS word
+  constexpr int kCopies = rs_hist_copies<BITS>(), kStride = kRadix + 1;
+  __shared__ unsigned s_hist[kRsHistCpw][kCopies * kStride];
   const RsPass plan = hdr->pass[pass];
   if (plan.skip) return;
   const unsigned *__restrict__ src = plan.src_is_tmp ? tmp : keys;
   const int shift = pass * BITS;
   const size_t chunk0 = static_cast<size_t>(blockIdx.x) * kRsHistCpw;
-  for (int i = threadIdx.x; i < kRsHistCpw * kRadix; i += kRsThreads) (&s_hist[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < kRsHistCpw * kCopies * kStride; i += kRsThreads) (&s_hist[0][0])[i] = 0;
   __syncthreads();
+  const unsigned my_copy = (threadIdx.x & (kCopies - 1)) * kStride;
 #pragma unroll 1
   for (int c = 0; c < kRsHistCpw; ++c) {
     const size_t chunk = chunk0 + c;
     if (chunk >= num_chunks) break;
-    unsigned *hist = s_hist[c];
+    unsigned *hist = s_hist[c] + my_copy;
     const size_t lo = chunk * tiles_per_chunk * kRsTile;
     size_t hi = lo + tiles_per_chunk * kRsTile;
     hi = hi < n ? hi : n;
@@ -358,13 +403,19 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
       atomicAdd(&hist[((src[i] ^ xor_mask) >> shift) & (kRadix - 1)], 1u);
   }
   __syncthreads();
+  auto count_of = [&](int c, int d) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < kCopies; ++k) sum += s_hist[c][k * kStride + d];
+    return sum;
+  };
   const bool vec = kRsHistCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;  // 16-byte aligned row pieces
   for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
     unsigned *row = counts + static_cast<size_t>(d) * num_chunks + chunk0;
     if (vec) {
-      *reinterpret_cast<u32x4 *>(row) = u32x4{s_hist[0][d], s_hist[1 % kRsHistCpw][d], s_hist[2 % kRsHistCpw][d], s_hist[3 % kRsHistCpw][d]};
+      *reinterpret_cast<u32x4 *>(row) = u32x4{count_of(0, d), count_of(1 % kRsHistCpw, d), count_of(2 % kRsHistCpw, d), count_of(3 % kRsHistCpw, d)};
     } else {
-      for (int c = 0; c < kRsHistCpw && chunk0 + c < num_chunks; ++c) row[c] = s_hist[c][d];
+      for (int c = 0; c < kRsHistCpw && chunk0 + c < num_chunks; ++c) row[c] = count_of(c, d);
     }
   }
 }
@@ -468,6 +519,52 @@ unsigned rank_fault_injection() {  // test hook: one swapped pair inside a digit
   return on;
 }
 
+// Stable rank of a wave's kRsKpt rows of keys among the wave's keys of the same digit; counts[] = the wave's digit
+// counters in LDS (zero on entry, the wave's digit counts on return).  ARANK: by returning LDS atomics — unless the
+// wave's keys crowd into few digits: the lanes of one atomic that hit the same counter are served one after the other
+// (two distinct key values: the scatter 28.6 -> 70 us per pass at 2^24 keys), the ballots cost the same whatever the
+// keys are (35 us).  The wave looks at two of its rows: if the first lane's digit is shared by kCrowd lanes or more, this
+// tile's 1024 keys are ranked by ballots.  The counters are the wave's own, so the choice is the wave's own too.
+template <int BITS, bool CHECK_VALID, bool ARANK>
+__device__ __forceinline__ void rs_rank_rows(const unsigned (&key)[kRsKpt], unsigned (&rank)[kRsKpt], unsigned *counts,
+                                             unsigned wave_first, unsigned valid_keys, int shift, unsigned xor_mask) {
+  constexpr int kRadix = 1 << BITS;
+  constexpr int kCrowd = BITS == 8 ? 8 : 16;  // uniform 4-bit digits put 4 lanes on a counter, uniform 8-bit digits 0.25
+  bool atomics = ARANK;
+  if (ARANK) {
+#pragma unroll
+    for (int j = 0; j < DBHIP_RS_CROWD_ROWS; ++j) {  // the rows whose loads come back first
+      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      const unsigned first = __builtin_amdgcn_readfirstlane(d);
+      if (__builtin_popcountll(__ballot(d == first)) >= kCrowd) atomics = false;
+    }
+  }
+  if (atomics) {
+#pragma unroll
+    for (int j = 0; j < kRsKpt; ++j) {
+      const bool valid = !CHECK_VALID || wave_first + j * kWave < valid_keys;
+      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+      rank[j] = valid ? atomicAdd(&counts[d], 1u) : 0u;  // see rank_by_lds_atomics() for why this is a stable rank
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < kRsKpt; ++j) {
+    const bool valid = !CHECK_VALID || wave_first + j * kWave < valid_keys;
+    const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
+    LaneMask m = match_digit<BITS>(d);
+    if (CHECK_VALID) {
+      const unsigned long long v = __ballot(valid);
+      m.lo &= static_cast<unsigned>(v);
+      m.hi &= static_cast<unsigned>(v >> 32);
+    }
+    const unsigned prior = lanes_before(m);
+    const unsigned c = counts[d];  // same address inside a digit group: LDS broadcast
+    rank[j] = c + prior;
+    if (valid && prior == 0) counts[d] = c + lanes_in(m);  // group leader
+  }
+}
+
 // ---- per pass, kernel 3: stable scatter of every chunk -------------------------------------------------
 // One tile of the scatter: stable rank inside each wave, digit offsets across waves, re-order through LDS, write out
 // in digit order.  FULL = the tile holds kRsTile keys: no per-key bounds checks (the kernel is VALU-bound — about 100
@@ -491,25 +588,7 @@ __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__
 
   // ---- stable rank of every key among the keys of its wave with the same digit
   unsigned rank[kRsKpt];
-#pragma unroll
-  for (int j = 0; j < kRsKpt; ++j) {
-    const bool valid = FULL || wave_first + j * kWave < valid_in_tile;
-    const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-    if (ARANK) {  // one returning LDS atomic: see rank_by_lds_atomics() for why this is a stable rank
-      rank[j] = valid ? atomicAdd(&s_cnt[wave][d], 1u) : 0u;
-      continue;
-    }
-    LaneMask m = match_digit<BITS>(d);
-    if (!FULL) {
-      const unsigned long long v = __ballot(valid);
-      m.lo &= static_cast<unsigned>(v);
-      m.hi &= static_cast<unsigned>(v >> 32);
-    }
-    const unsigned prior = lanes_before(m);
-    const unsigned c = s_cnt[wave][d];  // same address inside a digit group: LDS broadcast
-    rank[j] = c + prior;
-    if (valid && prior == 0) s_cnt[wave][d] = c + lanes_in(m);  // group leader
-  }
+  rs_rank_rows<BITS, !FULL, ARANK>(key, rank, s_cnt[wave], wave_first, valid_in_tile, shift, xor_mask);
   __syncthreads();
 
   // ---- digit owners: counts across waves -> wave-exclusive offsets, tile totals
@@ -694,23 +773,7 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
     for (int i = tid; i < kRsWaves * kRadix; i += kRsThreads) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     unsigned rank[kRsKpt];
-#pragma unroll
-    for (int j = 0; j < kRsKpt; ++j) {
-      const bool valid = wave_first + j * kWave < n;
-      const unsigned d = ((key[j] ^ xor_mask) >> shift) & (kRadix - 1);
-      if (ARANK) {
-        rank[j] = valid ? atomicAdd(&s_cnt[wave][d], 1u) : 0u;
-        continue;
-      }
-      LaneMask m = match_digit<BITS>(d);
-      const unsigned long long v = __ballot(valid);
-      m.lo &= static_cast<unsigned>(v);
-      m.hi &= static_cast<unsigned>(v >> 32);
-      const unsigned prior = lanes_before(m);
-      const unsigned c = s_cnt[wave][d];
-      rank[j] = c + prior;
-      if (valid && prior == 0) s_cnt[wave][d] = c + lanes_in(m);
-    }
+    rs_rank_rows<BITS, true, ARANK>(key, rank, s_cnt[wave], wave_first, n, shift, xor_mask);
     __syncthreads();
     unsigned tile_count = 0;
     if (tid < kRadix) {

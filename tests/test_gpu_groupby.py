@@ -123,6 +123,55 @@ def test_the_mode_choice_avoids_the_packed_tables_cliffs():
     assert int(plan.ws[4:8].view(torch.int32).item()) == 2
 
 
+@pytest.mark.parametrize("groups", [8192, 16384, 32768, 40000, 65536, 100000])
+@pytest.mark.parametrize("kind", ["one group", "90 % one group", "sorted keys", "runs of 24 and of 40 rows", "full-range values"])
+def test_rows_of_one_group_in_many_lanes(kind, groups):
+    """Tables with fewer than four lane copies sum a wave's rows of one group before the LDS add (groupby.hip
+    crowd_guard): crowds of every size, mixed with spread keys, in ranges the workgroup does not own, ragged ends."""
+    n = (1 << 20) + 3
+    rng = np.random.default_rng(17)
+    keys = po.gen_uniform_u32(n, 42, 0, groups - 1)
+    vals = po.gen_uniform_u32(n, 43, 1, 10000)
+    if kind == "one group":
+        keys[:] = groups - 1
+    elif kind == "90 % one group":
+        keys[rng.random(n) < 0.9] = groups // 3
+    elif kind == "sorted keys":
+        keys = np.sort(keys)
+    elif kind == "runs of 24 and of 40 rows":  # around the crowd threshold, four keys per lane apart
+        keys[: n // 256 * 256].reshape(-1, 256)[:, 0:96:4] = 5
+        keys[: n // 256 * 256].reshape(-1, 256)[:, 97:256:4] = groups - 2
+    else:
+        keys[:] = groups // 2
+        vals = po.gen_uniform_u32(n, 43, 0, 2**32 - 1)
+    assert np.array_equal(_run(keys, vals, groups), po.groupby_sum(keys, vals, groups))
+
+
+def test_one_hot_group_costs_no_multiple_of_uniform_keys():
+    """Round 3: 2^26 rows of one key took 251 us against 106 for uniform keys at 32768 groups (471 against 111 at 65536):
+    64 lanes queueing on one LDS word.  Now 114 / 200 us; the bounds leave room for the box."""
+    from dwarf_bench_amd import ops
+    n = 1 << 26
+    vals = ops.gen_uniform_u32(n, 43, 1, 10000)
+
+    def median_us(keys, groups):
+        plan = ops.GroupBySum(n, groups)
+        out = []
+        for _ in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            plan.launch(keys, vals)
+            b.record()
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b) * 1e3)
+        return sorted(out[1:])[2]
+
+    for groups, bound in ((32768, 1.6), (65536, 2.6)):
+        uniform = median_us(ops.gen_uniform_u32(n, 42, 0, groups - 1), groups)
+        hot = median_us(torch.full((n,), groups // 3, dtype=torch.int32, device="cuda"), groups)
+        assert hot < bound * uniform, (groups, hot, uniform)
+
+
 def test_skewed_keys():
     n, groups = 1 << 18, 65536
     keys = np.zeros(n, np.uint32)

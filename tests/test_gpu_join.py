@@ -125,6 +125,89 @@ def test_join_2_27_rows_skewed_keys_through_the_packed_histogram():
     assert torch.equal(build[ids[p + c - 1].to(torch.int64)], probe[hit])
 
 
+def _fmix32(h):
+    h = h.astype(np.uint64)
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def _keys_of_partition(n_build, partition, how_many):
+    """distinct keys that the build of n_build rows puts into one partition (join_lds.hip jl_pid: the high bits of
+    fmix32(key) * parts; parts as join_common.hpp jl_layout has them)"""
+    parts = 1
+    while 2048 * parts < n_build and parts < (1 << 20):
+        parts *= 2
+    cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
+    mine = cand[(_fmix32(cand) * parts) >> 32 == partition][:how_many]
+    assert mine.size == how_many
+    return mine.astype(np.uint32)
+
+
+def _check_grouped_join(build, probe):
+    """counts per probe row against numpy; ids a permutation of the build rows in which every key's rows are ONE run;
+    every hit's range starts and ends inside its key's run (with the count right, the range IS the run)"""
+    from dwarf_bench_amd import ops
+    plan = ops.HashJoin(len(build), len(probe))
+    plan.build(_dev(build))
+    plan.probe(_dev(probe))
+    pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in plan.result())
+    assert np.array_equal(cnt.astype(np.uint64), po.join_counts_fast(build, probe))
+    assert np.array_equal(np.sort(ids), np.arange(len(build), dtype=np.uint32))
+    in_order = build[ids]
+    assert np.count_nonzero(in_order[1:] != in_order[:-1]) + 1 == np.unique(build).size
+    hit = cnt > 0
+    assert np.array_equal(in_order[pos[hit]], probe[hit])
+    assert np.array_equal(in_order[pos[hit] + cnt[hit] - 1], probe[hit])
+
+
+@pytest.mark.parametrize("n", [(1 << 18) + 5, 1 << 22])  # one and two scatter levels
+@pytest.mark.parametrize("kind", ["every row one key", "every other row one key", "three hot keys",
+                                  "1500 keys of one partition, 40 rows each", "two giants and 1200 keys of a third"])
+def test_join_build_with_giant_partitions(kind, n):
+    """A partition far above its expected 2048 rows (hot keys) is counted and filled by all workgroups together
+    (join_lds.hip jl_giant_count / jl_giant_fill; from 2^18 build rows, giants above max(32768, n / 1024) rows)."""
+    rng = np.random.default_rng(23)
+    build = po.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = po.gen_uniform_u32(1 << 18, 43, 0, n - 1)
+    if kind == "every row one key":
+        build[:] = 777
+    elif kind == "every other row one key":
+        build[::2] = 123456789
+    elif kind == "three hot keys":
+        r = rng.random(n)
+        build[r < 0.3] = 5
+        build[(r >= 0.3) & (r < 0.6)] = 4000000000
+        build[(r >= 0.6) & (r < 0.9)] = 99
+    elif kind == "1500 keys of one partition, 40 rows each":  # (the partition's own ~1300 distinct keys come on top)
+        build[: 1500 * 40] = np.repeat(_keys_of_partition(n, 3, 1500), 40)
+        build = rng.permutation(build)
+    else:
+        build[: 1200 * 30] = np.repeat(_keys_of_partition(n, 0, 1200), 30)
+        build[100000:150000] = 31
+        build[150000:230000:2] = 32
+        build = rng.permutation(build)
+    probe[::7] = build[rng.integers(0, n, probe[::7].size)]  # probe rows that hit, hot keys among them
+    _check_grouped_join(build, probe)
+
+
+def test_a_giant_partition_with_too_many_keys_is_flagged():
+    """more than 3072 distinct keys in one partition: TABLE_FULL, as in the per-partition build — and no stray store"""
+    from dwarf_bench_amd import _capi, ops
+    n = 1 << 18
+    build = po.gen_uniform_u32(n, 42, 0, n - 1)
+    build[: 3500 * 20] = np.repeat(_keys_of_partition(n, 1, 3500), 20)
+    plan = ops.HashJoin(n, 16)
+    plan.build(_dev(build))
+    plan.probe(_dev(build[:16]))
+    assert ops.workspace_status(plan.ws) & ops.DEV_TABLE_FULL
+    with pytest.raises(_capi.DbhipError):
+        plan.result()
+
+
 def test_ujoin_reference_fixture_shape(golden_dir):
     """unique-key payload join vs seq_join (join_helpers.hpp:86-104) as a multiset of rows (join.cpp:133)."""
     from dwarf_bench_amd import ops

@@ -6,12 +6,15 @@ the contract numbers come from bench.py.
 
   scan            two-launch vs dense copy_if at 2^28 rows over a selectivity sweep (median of 9)
   sort [lg]       2^lg-key sort, 8- and 4-bit digits (drop-max-mean of 9, refresh copy subtracted); default lg 24
-  sort-only       three 2^24 sorts and nothing else (counter collection; SORT_BITS=4|8)
+  sort-only       three 2^24 sorts and nothing else (counter collection; SORT_BITS=4|8, SORT_SHAPE=<index into sort-shapes' list>)
   groupby         2^26 rows at 2^16 / 2^15 / 2^10 / 64 groups (drop-max-mean of 9)
   groupby-shapes  more than 32768 groups over row counts, group counts and value ranges (median of 5): run it with
                   DBHIP_GB_PACKED=0 beside the default to see what the kernel's choice between its two large-table modes
                   buys and that it costs nothing where the packed table would be slow
+  groupby-skew    2^26 rows whose keys crowd into one or a few groups, at 64 .. 2^16 groups (median of 5)
+  sort-shapes [lg] 2^lg keys of eight distributions (few distinct values, sorted, reversed, skewed ...; median of 5)
   join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
+  join-skew [lg]  the same over key shapes (hot keys, strided keys, sorted, few distinct keys; median of 3)
   partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
   reduce          2^28-row reduce (median of 15; DBHIP_RED_WGS)
   xscan [lg]      exclusive scan of 2^lg uint32, aligned (one launch) and offset by one element (three launches)
@@ -57,6 +60,11 @@ def u64(t):
     return t.to(torch.int64) & 0xFFFFFFFF
 
 
+def bits32(t):
+    """int64 values in [0, 2^32) as the int32 tensor holding the same bits (how the C ABI takes uint32 keys)"""
+    return ((t + 2**31) % 2**32 - 2**31).to(torch.int32)
+
+
 def scan(_):
     n = 1 << 28
     src = ops.gen_uniform_u32(n, 42, 1, 10000)
@@ -93,7 +101,7 @@ def sort(lg):
 
 def sort_only(_):
     n = 1 << 24
-    keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    keys0 = _shape_keys(n, SHAPES[int(os.environ.get("SORT_SHAPE", "0"))])
     keys = keys0.clone()
     plan = ops.RadixSort(n, int(os.environ.get("SORT_BITS", "8")))
     for _i in range(3):
@@ -133,6 +141,78 @@ def groupby_shapes(_):
         del keys, vals, plan
 
 
+def _shape_keys(n, kind):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    if kind == "uniform 32-bit":
+        return ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    if kind == "[1, 10000]":
+        return ops.gen_uniform_u32(n, 42, 1, 10000)
+    if kind == "two values":
+        return bits32(torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.int64) * 0xFFFFFFFF)
+    if kind == "16 values":
+        return bits32(torch.randint(0, 16, (n,), device="cuda", generator=g, dtype=torch.int64) * 0x11111111)
+    if kind == "90 % one value":
+        k = torch.randint(0, 2**32, (n,), device="cuda", generator=g, dtype=torch.int64)
+        hot = torch.rand(n, device="cuda", generator=g) < 0.9
+        return bits32(torch.where(hot, torch.full_like(k, 0x9E3779B9), k))
+    if kind == "sorted":
+        return bits32(torch.sort(u64(ops.gen_uniform_u32(n, 42, 0, 2**32 - 1))).values)
+    if kind == "reversed":
+        return bits32(torch.sort(u64(ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)), descending=True).values)
+    if kind == "geometric":  # key = 2^32 * u^8: most keys small, every byte still varies
+        u = torch.rand(n, device="cuda", generator=g, dtype=torch.float64)
+        return bits32((u ** 8 * 4294967295.0).to(torch.int64))
+    raise ValueError(kind)
+
+
+SHAPES = ("uniform 32-bit", "[1, 10000]", "two values", "16 values", "90 % one value", "sorted", "reversed", "geometric")
+
+
+def sort_shapes(lg):
+    n = 1 << (lg or 24)
+    for kind in SHAPES:
+        keys0 = _shape_keys(n, kind)
+        keys = keys0.clone()
+        ref = torch.sort(u64(keys0)).values
+        res = []
+        for bits in (8, 4):
+            plan = ops.RadixSort(n, bits)
+
+            def run():
+                keys.copy_(keys0)
+                plan.launch(keys)
+
+            t = median(times(run, 5)) - median(times(lambda: keys.copy_(keys0), 5))
+            run()
+            ok = bool(torch.equal(u64(keys), ref)) and ops.workspace_status(plan.ws) == 0
+            res.append(f"{bits}-bit {t:8.1f} us {'ok' if ok else 'WRONG'}")
+        print(f"{TAG:16s} 2^{lg or 24} {kind:16s}: " + "   ".join(res), flush=True)
+
+
+def groupby_skew(_):
+    n = 1 << 26
+    for groups in (64, 1 << 10, 1 << 12, 1 << 14, 1 << 15, 1 << 16):
+        for kind in ("uniform", "one group", "90 % one group", "16 groups", "sorted keys"):
+            g = torch.Generator(device="cuda").manual_seed(7)
+            keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+            if kind == "one group":
+                keys = torch.full_like(keys, groups // 3)
+            elif kind == "90 % one group":
+                hot = torch.rand(n, device="cuda", generator=g) < 0.9
+                keys = torch.where(hot, torch.full_like(keys, groups // 3), keys)
+            elif kind == "16 groups":
+                keys = bits32(u64(keys) % 16 * (groups // 16))
+            elif kind == "sorted keys":
+                keys = bits32(torch.sort(u64(keys)).values)
+            vals = ops.gen_uniform_u32(n, 43, 1, 10000)
+            plan = ops.GroupBySum(n, groups)
+            t = median(times(lambda: plan.launch(keys, vals), 5))
+            ref = torch.zeros(groups, dtype=torch.int64, device="cuda").index_add_(0, u64(keys), u64(vals))
+            ok = bool(torch.equal(u64(plan.result()), ref & 0xFFFFFFFF))
+            print(f"{TAG:16s} G={groups:6d} {kind:16s}: {t:9.1f} us {'ok' if ok else 'WRONG'}", flush=True)
+            del keys, vals, plan
+
+
 def join(lg):
     lg = lg or 26
     n = 1 << lg
@@ -160,6 +240,54 @@ def join(lg):
     ok = int(rj.cnt.to(torch.int64).sum()) == total
     print(f"{TAG:20s} 2^{lg}: build {b:8.1f} probe {p:8.1f} total {b + p:8.1f} us | radix join {r:8.1f} us "
           f"(partition one side {pb:7.1f}, match {m:7.1f}) matches {'equal' if ok else 'DIFFER'}", flush=True)
+
+
+def _matches(build, probe):
+    """number of (build row, probe row) pairs with equal keys, by torch"""
+    bk, bc = torch.unique(u64(build), return_counts=True)
+    pk, pc = torch.unique(u64(probe), return_counts=True)
+    at = torch.searchsorted(bk, pk).clamp(max=bk.numel() - 1)
+    hit = bk[at] == pk
+    return int((bc[at][hit] * pc[hit]).sum())
+
+
+def join_skew(lg):
+    lg = lg or 26
+    n = 1 << lg
+    g = torch.Generator(device="cuda").manual_seed(7)
+    uni_b, uni_p = ops.gen_uniform_u32(n, 42, 0, n - 1), ops.gen_uniform_u32(n, 43, 0, n - 1)
+    hot = torch.rand(n, device="cuda", generator=g) < 0.5
+
+    def shapes():
+        yield "uniform", uni_b, uni_p
+        yield "half the build rows one key", torch.where(hot, torch.full_like(uni_b, 12345), uni_b), uni_p
+        yield "half the probe rows one key", uni_b, torch.where(hot, torch.full_like(uni_p, 12345), uni_p)
+        yield "keys are multiples of 65536", bits32(u64(uni_b) % 1024 * 65536), bits32(u64(uni_p) % 2048 * 65536)
+        yield "keys are multiples of 1024", bits32(u64(uni_b) % 65536 * 1024), bits32(u64(uni_p) % 65536 * 1024)
+        yield "sorted", bits32(torch.sort(u64(uni_b)).values), bits32(torch.sort(u64(uni_p)).values)
+        yield "1024 distinct keys on the build side", bits32(u64(uni_b) % 1024), uni_p
+
+    for kind, build, probe in shapes():
+        plan = ops.HashJoin(n, n)
+        plan.build(build)
+        plan.probe(probe)
+        b = median(times(lambda: plan.build(build), 3, warm=0))
+        p = median(times(lambda: plan.probe(probe), 3, warm=0))
+        plan.result()
+        total = int(plan.cnt.to(torch.int64).sum())
+        del plan
+        rj = ops.RadixJoin(n, n)
+
+        def radix():
+            rj.partition_build(build)
+            rj.partition_probe(probe)
+            rj.match()
+
+        r = median(times(radix, 3, warm=1))
+        rj.result()
+        ok = int(rj.cnt.to(torch.int64).sum()) == total == _matches(build, probe)
+        del rj
+        print(f"{TAG:16s} 2^{lg} {kind:38s}: build {b:9.1f} probe {p:9.1f} | radix join {r:9.1f} us  matches {'equal' if ok else 'DIFFER'}", flush=True)
 
 
 def partition(_):
@@ -243,12 +371,24 @@ def graph(_):
 def launch_join(lg):
     n = 1 << (lg or 26)
     build, probe = ops.gen_uniform_u32(n, 42, 0, n - 1), ops.gen_uniform_u32(n, 43, 0, n - 1)
+    hot = os.environ.get("JOIN_HOT", "")  # build | probe: every other row of that side carries one key
+    if hot == "build":
+        build[::2] = 12345
+    if hot == "probe":
+        probe[::2] = 12345
     plan = ops.HashJoin(n, n)
     for _i in range(5):
         plan.build(build)
         plan.probe(probe)
     torch.cuda.synchronize()
     plan.result()
+    if os.environ.get("JOIN_RADIX"):
+        rj = ops.RadixJoin(n, n)
+        for _i in range(3):
+            rj.partition_build(build)
+            rj.partition_probe(probe)
+            rj.match()
+        rj.result()
     print("ok")
 
 
@@ -282,7 +422,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "join": join, "partition": partition,
+MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
