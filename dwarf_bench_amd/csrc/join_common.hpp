@@ -61,7 +61,7 @@ inline bool jl_use_ujoin(size_t n_build) {
 // A GIANT partition: one hot key (or a few) gives a partition far more rows than one workgroup should walk alone —
 // every other row of 2^24 carrying one key made the build 22.5 ms against 0.3 ms.  A partition above jl_giant_rows(n)
 // rows is left out by the per-partition build and counted / filled by all workgroups together, slice by slice
-// (jl_giant_count / jl_giant_fill in join_lds.hip).  There are fewer than n / jl_giant_rows(n) of them: the scratch
+// (jl_giant_count / jl_giant_ids in join_lds.hip).  There are fewer than n / jl_giant_rows(n) of them: the scratch
 // below (list, finished-slice counters, per giant the key counts and the id cursors of its sub-table's slots) is sized
 // for that, so no giant is ever left to the slow path.  Below 2^18 build rows the two extra launches would cost more
 // than a giant can (a partition of 2^17 rows: 0.3 ms): the path is off, jl_max_giants = 0.
@@ -75,9 +75,17 @@ inline unsigned jl_max_giants(size_t n) {
 // scratch: count, pad[3] | part[max] | done[max] | counts[max][kJlSubSlots] | cursors[max][kJlSubSlots]; the first
 // jl_giant_header_bytes are cleared with the partitioner's meta words, a giant's counts by the workgroup that lists it
 inline size_t jl_giant_header_bytes(unsigned max_giants) { return max_giants ? 16 + 8 * static_cast<size_t>(max_giants) : 0; }
-inline size_t jl_giant_bytes(unsigned max_giants) {
-  return max_giants ? align_up(jl_giant_header_bytes(max_giants), 16) + static_cast<size_t>(max_giants) * kJlSubSlots * 8 : 0;
+inline size_t jl_giant_bytes(unsigned max_giants, bool with_tables = false) {
+  if (!max_giants) return 0;
+  const size_t tables = with_tables ? static_cast<size_t>(max_giants) * (kJlSubSlots + 1) * 8 : 0;  // the radix join publishes no table: its giants' sub-tables live here (+ a sentinel slot each)
+  return align_up(jl_giant_header_bytes(max_giants), 16) + static_cast<size_t>(max_giants) * kJlSubSlots * 8 + tables;
 }
+// the radix join's list also takes partitions whose PROBE side is that large
+inline unsigned jr_max_giants(size_t n_build, size_t n_probe) {
+  if (n_build < (static_cast<size_t>(1) << 18) && n_probe < (static_cast<size_t>(1) << 18)) return 0u;
+  return static_cast<unsigned>(n_build / jl_giant_rows(n_build) + n_probe / jl_giant_rows(n_probe) + 2);
+}
+constexpr unsigned kJlMaxGiantList = 2052;  // >= 2 * (1024 + 1) + 1: the giant kernels' LDS list
 
 struct JlLayout {
   unsigned parts, k1, k2, log2_k2, max_giants;

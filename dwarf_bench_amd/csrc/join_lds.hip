@@ -661,6 +661,33 @@ __device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigne
   return kJlSubSlots;
 }
 
+// ---- lanes of a wave that meet on one LDS counter -----------------------------------------------------------------
+// A hot key is many rows of a wave on one counter of the sub-table, and the LDS serves the lanes of one atomic that hit
+// the same word one after the other.  jl_take: every live lane takes the next value of its counter (UP: returns the old
+// value, the counter grows; down: returns old - 1, the counter shrinks); when kJlCrowd lanes or more share the first live
+// lane's counter, one of them adds for all and the others derive their values from its result.  `id` names the counter
+// (lanes with the same id pass the same pointer).  Every lane of the wave must call it together.
+constexpr unsigned kJlCrowd = 16;
+template <bool UP>
+__device__ __forceinline__ unsigned jl_take(unsigned *counter, unsigned id, bool live) {
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const unsigned long long act = __ballot(live);
+  if (act == 0) return 0u;  // (uniform)
+  const unsigned first = __builtin_amdgcn_readlane(id, __builtin_ctzll(act));
+  const bool same = live && id == first;
+  const unsigned long long crowd = __ballot(same);
+  const unsigned c = static_cast<unsigned>(__builtin_popcountll(crowd));
+  if (c >= kJlCrowd) {  // (uniform)
+    const unsigned leader = static_cast<unsigned>(__builtin_ctzll(crowd));
+    unsigned old = 0;
+    if (lane == leader) old = UP ? atomicAdd(counter, c) : atomicSub(counter, c);
+    old = __builtin_amdgcn_readlane(old, leader);
+    if (same) return UP ? old + mbcnt(crowd) : old - 1u - mbcnt(crowd);
+  }
+  if (!live) return 0u;
+  return UP ? atomicAdd(counter, 1u) : atomicSub(counter, 1u) - 1u;
+}
+
 // Barriers of the build kernel order LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the
 // next partition's prefetched rows and for every id / table store still on its way to memory (DBHIP_JL_FULL_BARRIER=1
 // restores it for A/B timing).
@@ -680,9 +707,18 @@ struct JlMatchArgs {
 };
 // The giant partitions' scratch (join_common.hpp: jl_giant_bytes): max == 0 switches the path off.
 struct JlGiants {
-  unsigned *base;           // count, pad[3] | part[max] | done[max] | counts[max][kJlSubSlots] | cursors[max][kJlSubSlots]
+  unsigned *base;           // count, pad[3] | part[max] | done[max] | counts[max][kJlSubSlots] | cursors[max][kJlSubSlots] | tables
   unsigned max;
   unsigned long long rows;  // a partition with more rows than this is a giant
+  unsigned long long probe_rows;  // radix join: ... or with more probe rows than this
+  unsigned with_tables;     // radix join: the giants' sub-tables are in the scratch (kJlSubSlots + 1 slots each), not in `table`
+  __host__ __device__ u32x2 *scratch_table(unsigned g) const {
+    return reinterpret_cast<u32x2 *>(cursors(max)) + static_cast<size_t>(g) * (kJlSubSlots + 1);
+  }
+  __host__ __device__ u32x2 *sub_table(u32x2 *table, unsigned g, size_t part) const {
+    if (with_tables) return scratch_table(g);
+    return table + part * kJlSubSlots;
+  }
   __host__ __device__ unsigned *count() const { return base; }
   __host__ __device__ unsigned *part() const { return base + 4; }
   __host__ __device__ unsigned *done() const { return base + 4 + max; }
@@ -692,7 +728,7 @@ struct JlGiants {
   __host__ __device__ unsigned *cursors(unsigned g) const { return counts(max) + static_cast<size_t>(g) * kJlSubSlots; }
 };
 template <bool kMatch>
-__global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigned *__restrict__ pkeys,
+__global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu(6))) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
                                                                    u32x2 *__restrict__ table, unsigned parts,
@@ -732,17 +768,34 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     asm volatile("v_mov_b32 %0, %0" : "+v"(carry[r].y));
   }
   while (true) {
-    if (!kMatch && giants.max != 0 && hi - lo > giants.rows) {  // (uniform over the workgroup)
-      // a giant partition (join_common.hpp): listed for jl_giant_count / jl_giant_fill, which all workgroups share, and
-      // published here as an EMPTY sub-table — that is the state their claims of its slots start from
+    // the offsets this step needs, requested together: the next partition's rows and (radix join) this partition's probe rows
+    const size_t npart = part + gridDim.x;
+    size_t nlo = 0, nhi = 0, slo = 0, shi = 0;
+    if (npart < parts) {
+      nlo = starts[npart];
+      nhi = starts[npart + 1];
+    }
+    if (kMatch) {
+      slo = match.sstarts[part];
+      shi = match.sstarts[part + 1];
+    }
+    if (giants.max != 0 && (hi - lo > giants.rows || (kMatch && shi - slo > giants.probe_rows))) {  // (uniform)
+      // a giant partition (join_common.hpp): listed for the jl_giant_* kernels, which all workgroups share.  Build: it is
+      // published here as an EMPTY sub-table — the state their claims of its slots start from.  Radix join: nothing of
+      // it is done here, neither side; its sub-table will be one of the scratch tables, emptied here.
       if (tid == 0) s_end = atomicAdd(giants.count(), 1u);
       JL_BUILD_BARRIER();
       const unsigned slot = s_end;
       JL_BUILD_BARRIER();  // (s_end is written again below)
-      if (slot < giants.max) {  // always: fewer than n / giants.rows partitions can be this large
+      if (slot < giants.max) {  // always: the list is sized for every partition that can be this large
         if (tid == 0) giants.part()[slot] = static_cast<unsigned>(part);
         unsigned *gc = giants.counts(slot);
         for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) gc[i] = 0;
+        if (kMatch) {
+          u32x2 *sub = giants.scratch_table(slot);
+          for (unsigned i = tid; i < kJlSubSlots + 1; i += kJlBuildThreads) sub[i] = u32x2{kEmptyKey, 0u};
+          shi = slo;
+        }
         hi = lo;
       }
     }
@@ -753,14 +806,10 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     u32x2 cur[kJlPre];
 #pragma unroll
     for (int r = 0; r < kJlPre; ++r) cur[r] = carry[r];
-    const size_t npart = part + gridDim.x;
-    size_t nlo = 0, nhi = 0;
     u32x2 pre[kJlPre];  // the next partition's rows, in flight
 #pragma unroll
     for (int r = 0; r < kJlPre; ++r) pre[r] = u32x2{0u, 0u};
     if (npart < parts) {
-      nlo = starts[npart];
-      nhi = starts[npart + 1];
 #pragma unroll
       for (int r = 0; r < kJlPre; ++r) {
         const size_t i = nlo + tid + static_cast<size_t>(r) * kJlBuildThreads;
@@ -770,10 +819,7 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     // radix join: this partition's first probe rows (four consecutive ones per lane) are requested now and arrive
     // while the sub-table is built
     u32x2 srow[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
-    size_t slo = 0, shi = 0;
     if (kMatch) {
-      slo = match.sstarts[part];
-      shi = match.sstarts[part + 1];
       const size_t j0 = slo + 4 * static_cast<size_t>(tid);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -811,10 +857,22 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
     // its rank (so the cached rows of a key hold the ranks 0 .. k-1 and these rows own the ranks behind them)
     const bool overflow = hi - lo > static_cast<size_t>(kJlCached) * kJlBuildThreads;  // uniform over the workgroup
     if (overflow) {
+      // (four rows per lane in flight and crowds of one key added by one lane, round 3: a partition of 2^16 rows of one
+      //  key took a workgroup 2.6 ns per row with one load in flight and every lane's atomic on the same word)
       JL_BUILD_BARRIER();
-      for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-        const unsigned s = jl_claim(lk, jl_row(pkeys, prids, i).x, status);
-        if (s < kJlSubSlots) atomicAdd(&lc[s], 1u);
+      for (size_t i0 = lo + static_cast<size_t>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+        u32x2 row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const size_t i = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid;
+          row[q] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool have = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid < hi;
+          const unsigned s = have ? jl_claim(lk, row[q].x, status) : kJlSubSlots;
+          (void)jl_take<true>(&lc[s < kJlSubSlots ? s : 0u], s, s < kJlSubSlots);
+        }
       }
     }
     JL_BUILD_BARRIER();
@@ -948,15 +1006,27 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
       // range downwards, decrementing a cursor that starts at the next slot's first position (for the last slot:
       // s_end) — after a barrier: the publish and the cached rows above still needed those words intact
       JL_BUILD_BARRIER();
-      for (size_t i = lo + tid + static_cast<size_t>(kJlCached) * kJlBuildThreads; i < hi; i += kJlBuildThreads) {
-        const u32x2 row = jl_row(pkeys, prids, i);
-        const unsigned key = row.x;
-        if (key == kEmptyKey) continue;
-        unsigned s = jl_home_slot(fmix32(key));
-        for (unsigned tries = 0; tries < kJlSubSlots && lk[s] != key; ++tries) s = jl_next_slot(s);
-        if (lk[s] != key) continue;
-        unsigned *cursor = s + 1 < kJlSubSlots ? &lp[s + 1] : &s_end;
-        ids[atomicSub(cursor, 1u) - 1u] = row.y;
+      for (size_t i0 = lo + static_cast<size_t>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+        u32x2 row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const size_t i = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid;
+          row[q] = i < hi ? jl_row(pkeys, prids, i) : u32x2{kEmptyKey, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned key = row[q].x;
+          unsigned s = kJlSubSlots;
+          if (key != kEmptyKey) {  // (a missing row reads as the sentinel key)
+            s = jl_home_slot(fmix32(key));
+            for (unsigned tries = 0; tries < kJlSubSlots && lk[s] != key; ++tries) s = jl_next_slot(s);
+            if (lk[s] != key) s = kJlSubSlots;
+          }
+          const bool live = s < kJlSubSlots;
+          unsigned *cursor = live && s + 1 < kJlSubSlots ? &lp[s + 1] : &s_end;
+          const unsigned at = jl_take<false>(cursor, s, live);
+          if (live) ids[at] = row[q].y;
+        }
       }
     }
     if (npart >= parts) break;
@@ -979,39 +1049,20 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_build_kernel(const unsigne
 //                   and adds the slice's count to that slot's counter — one memory-side atomic per slice and key, not per
 //                   row.  The workgroup that finishes a giant's LAST slice (a counter per giant) scans the slot counters:
 //                   first id position of every slot -> the table's position words and the slot cursors.
-//   jl_giant_fill   the slices are counted again the same way; per distinct key ONE returning add on the slot's cursor
+//   jl_giant_ids   the slices are counted again the same way; per distinct key ONE returning add on the slot's cursor
 //                   reserves the slice's share of the key's id range, then every row takes its place inside the share
 //                   from an LDS cursor and stores its row id.
 // Lanes of a wave that meet on one LDS counter (that is what a hot key is) are added by one lane: jl_take.
 // Nothing here waits for another workgroup.
 constexpr unsigned kJlSlice = 8192;        // rows of a slice: 16 per thread
 constexpr int kJlGiantThreads = 512;
-constexpr unsigned kJlCrowd = 16;          // lanes on one counter from which one of them adds for all
-
-// every live lane takes the next value of counter cnt[s] (returns it; cnt[s] += number of live lanes on s)
-__device__ __forceinline__ unsigned jl_take(unsigned *cnt, unsigned s, bool live) {
-  const unsigned lane = threadIdx.x & (kWave - 1);
-  const unsigned long long act = __ballot(live);
-  if (act == 0) return 0u;  // (uniform)
-  const unsigned first = __builtin_amdgcn_readlane(s, __builtin_ctzll(act));
-  const bool same = live && s == first;
-  const unsigned long long crowd = __ballot(same);
-  const unsigned c = static_cast<unsigned>(__builtin_popcountll(crowd));
-  if (c < kJlCrowd) return live ? atomicAdd(&cnt[s], 1u) : 0u;
-  const unsigned leader = static_cast<unsigned>(__builtin_ctzll(crowd));
-  unsigned old = 0;
-  if (lane == leader) old = atomicAdd(&cnt[first], c);
-  old = __builtin_amdgcn_readlane(old, leader);
-  if (same) return old + mbcnt(crowd);
-  return live ? atomicAdd(&cnt[s], 1u) : 0u;
-}
-
 // the slices of the listed giants as one flat list: s_first[g] = index of giant g's first slice (s_first[ng] = total)
 __device__ __forceinline__ unsigned jl_giant_slices(const JlGiants &giants, const unsigned long long *__restrict__ starts,
                                                     unsigned *s_first, unsigned *s_wsum, unsigned *ng_out) {
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned ng = *giants.count();
   ng = ng < giants.max ? ng : giants.max;
+  ng = ng < kJlMaxGiantList - 1 ? ng : kJlMaxGiantList - 1;
   *ng_out = ng;
   if (ng == 0) return 0u;
   unsigned total = 0;
@@ -1064,7 +1115,7 @@ __device__ __forceinline__ void jl_slice_count(const u32x2 *__restrict__ rows, s
     for (int q = 0; q < 4; ++q) {
       const bool have = i0 + static_cast<size_t>(q) * kJlGiantThreads + tid < b;
       const unsigned sl = have ? jl_claim(lk, r[q].x, status) : kJlSubSlots;
-      (void)jl_take(lc, sl < kJlSubSlots ? sl : 0u, sl < kJlSubSlots);
+      (void)jl_take<true>(&lc[sl < kJlSubSlots ? sl : 0u], sl, sl < kJlSubSlots);
     }
   }
   __syncthreads();
@@ -1093,7 +1144,7 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
                                                                          u32x2 *table, unsigned pos_bits, JlGiants giants,
                                                                          unsigned *status) {
   __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
-  __shared__ unsigned s_first[1026], s_wsum[kJlGiantThreads / kWave], s_last;
+  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave], s_last;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned ng;
   const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
@@ -1104,23 +1155,26 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
     const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
     const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
     jl_slice_count(rows, a, b, lk, lc, status);
-    u32x2 *sub = table + static_cast<size_t>(part) * kJlSubSlots;
+    u32x2 *sub = giants.sub_table(table, g, part);
     unsigned *gcount = giants.counts(g);
     for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
       const unsigned c = lc[i];
       if (c) {
         const unsigned gs = jl_giant_slot(sub, lk[i], true, status);
-        if (gs < kJlSubSlots) atomicAdd(&gcount[gs], c);
+        if (gs < kJlSubSlots) {
+          const unsigned before = atomicAdd(&gcount[gs], c);
+          asm volatile("" ::"v"(before));  // the lane waits for the atomic's answer: the add has been performed
+        }
       }
     }
-    // the last slice of a giant to get here turns the slot counters into positions (every add above is performed before
-    // this workgroup's tick on the giant's counter: fence, barrier, then the tick)
-    __threadfence();
+    // The last slice of a giant to get here turns the slot counters into positions.  Counter adds, tick and the reads
+    // below are all memory-side atomics, every lane has its adds' answers before the barrier, the tick comes after it:
+    // no fence.  (With __threadfence() on either side of the tick — a write-back and an invalidation of the XCD's whole
+    // L2 each — this kernel took 2.1 ms for 500 giants of 2^16 rows: 9 slices each, every one stalling its XCD twice.)
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(&giants.done()[g], 1u) + 1u == s_first[g + 1] - s_first[g] ? 1u : 0u;
     __syncthreads();
     if (s_last) {  // (uniform)
-      __threadfence();
       constexpr unsigned kPer = kJlSubSlots / kJlGiantThreads;
       unsigned c[kPer], mine = 0;
 #pragma unroll
@@ -1144,17 +1198,18 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
         reinterpret_cast<unsigned *>(sub + slot)[1] = pos_bits < 32 ? (run | (f << pos_bits)) : run;
         run += c[j];
       }
+      if (giants.with_tables && tid == kJlGiantThreads - 1) sub[kJlSubSlots] = u32x2{kEmptyKey, run};  // the scratch table's sentinel
     }
     __syncthreads();  // lk / lc / s_wsum / s_last are reused by the next slice
   }
 }
 
-__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_fill_kernel(const u32x2 *__restrict__ rows,
+__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32x2 *__restrict__ rows,
                                                                         const unsigned long long *__restrict__ starts,
                                                                         u32x2 *table, JlGiants giants,
                                                                         unsigned *__restrict__ ids, unsigned *status) {
   __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
-  __shared__ unsigned s_first[1026], s_wsum[kJlGiantThreads / kWave];
+  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave];
   const unsigned tid = threadIdx.x;
   unsigned ng;
   const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
@@ -1165,7 +1220,7 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_fill_kernel(const u3
     const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
     const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
     jl_slice_count(rows, a, b, lk, lc, status);
-    u32x2 *sub = table + static_cast<size_t>(part) * kJlSubSlots;
+    u32x2 *sub = giants.sub_table(table, g, part);
     unsigned *cursor = giants.cursors(g);
     // the slice's share of every key's id range: lc[i] becomes the first position of the share
     for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
@@ -1200,7 +1255,7 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_fill_kernel(const u3
           }
         }
         const bool live = sl < kJlSubSlots;
-        const unsigned pos = jl_take(lc, live ? sl : 0u, live);
+        const unsigned pos = jl_take<true>(&lc[live ? sl : 0u], sl, live);
         if (live && pos - static_cast<unsigned>(lo) < static_cast<unsigned>(hi - lo)) ids[pos] = r[q].y;  // (outside: only behind a full table)
       }
     }
@@ -1209,10 +1264,17 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_fill_kernel(const u3
 }
 
 // one probe row: slot {key, first position | count field} by linear probing inside the key's sub-table
+__device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out);
 __device__ __forceinline__ void jl_probe_row(unsigned key, const u32x2 *__restrict__ table, unsigned parts, unsigned pos_bits,
                                              unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out) {
   const unsigned h = fmix32(key);
-  const u32x2 *sub = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
+  jl_probe_sub(key, h, table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots, pos_bits,
+               pos_mask, cnt_esc, pos_out, cnt_out);
+}
+// the same inside a given sub-table (h = fmix32(key))
+__device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out) {
   unsigned s = jl_home_slot(h), pos = 0, cnt = 0;
   for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {  // the sentinel never matches
     const u32x2 e = sub[s];
@@ -1228,6 +1290,34 @@ __device__ __forceinline__ void jl_probe_row(unsigned key, const u32x2 *__restri
   }
   *pos_out = pos;
   *cnt_out = cnt;
+}
+
+// radix join: the probe rows of the listed partitions against their scratch sub-tables — slices of kJlSlice rows over
+// all workgroups, one 8-byte gather per row (a hot key's slot is one cache line for everybody); results at the row's
+// place in the probe side's partition order, like the fused kernel's
+__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_probe_kernel(JlMatchArgs match, unsigned pos_bits, JlGiants giants) {
+  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave];
+  const unsigned tid = threadIdx.x;
+  unsigned ng;
+  const unsigned items = jl_giant_slices(giants, match.sstarts, s_first, s_wsum, &ng);
+  const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
+  const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    const unsigned g = jl_giant_of(s_first, ng, item);
+    const unsigned part = giants.part()[g];
+    const size_t slo = match.sstarts[part], shi = match.sstarts[part + 1];
+    const size_t a = slo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
+    const size_t b = a + kJlSlice < shi ? a + kJlSlice : shi;
+    const u32x2 *sub = giants.scratch_table(g);
+    for (size_t j = a + tid; j < b; j += kJlGiantThreads) {
+      const u32x2 row = match.spairs[j];
+      unsigned pos, cnt;
+      jl_probe_sub(row.x, fmix32(row.x), sub, pos_bits, pos_mask, cnt_esc, &pos, &cnt);
+      match.out_rid[j] = row.y;
+      match.out_pos[j] = pos;
+      match.out_cnt[j] = cnt;
+    }
+  }
 }
 
 #ifndef DBHIP_JL_PROBE_ROWS
@@ -1501,6 +1591,10 @@ int jl_partition_rows(const unsigned *build_keys, const unsigned *row_ids, size_
 }
 
 size_t jl_build_lds_bytes() { return 2 * static_cast<size_t>(kJlSubSlots) * sizeof(unsigned); }
+bool jl_no_giants() {  // DBHIP_JL_NO_GIANTS=1: every partition through the per-partition kernel, whatever its size (A/B timing)
+  static const bool off = [] { const char *v = getenv("DBHIP_JL_NO_GIANTS"); return v && v[0] == '1'; }();
+  return off;
+}
 unsigned jl_build_grid(unsigned parts, const DeviceInfo &dev) {
   // as many 512-thread workgroups per CU as their LDS tables allow (24 KiB each at 3072 slots: four)
   const size_t lds = jl_build_lds_bytes();
@@ -1523,9 +1617,8 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
   // giant partitions (join_common.hpp): listed by the build kernel, counted and filled by two launches of their own
-  JlGiants giants{nullptr, 0u, ~0ull};
-  static const bool no_giants = [] { const char *v = getenv("DBHIP_JL_NO_GIANTS"); return v && v[0] == '1'; }();  // A/B knob
-  if (L.max_giants && !no_giants) {
+  JlGiants giants{nullptr, 0u, ~0ull, ~0ull, 0u};
+  if (L.max_giants && !jl_no_giants()) {
     giants.base = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + L.giant_off);
     giants.max = L.max_giants;
     giants.rows = jl_giant_rows(n);
@@ -1539,7 +1632,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
     const unsigned grid = static_cast<unsigned>(dev.cus) * (2048 / kJlGiantThreads);
     hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
                        p.starts, p.table, jl_pos_bits(n), giants, p.status);
-    hipLaunchKernelGGL(jl_giant_fill_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
+    hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
                        p.starts, p.table, giants, ids, p.status);
   }
   return launch_status();
@@ -1549,8 +1642,8 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
 // workspace: header | build side: pairs a, pairs b, meta | probe side: pairs a, pairs b, meta
 namespace {
 struct JrLayout {
-  unsigned parts, k1, k2, log2_k2;
-  size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, total;
+  unsigned parts, k1, k2, log2_k2, max_giants;
+  size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, giant_off, total;
 };
 JrLayout jr_layout(size_t n_build, size_t n_probe) {
   const JlLayout G = jl_layout(n_build);
@@ -1565,7 +1658,9 @@ JrLayout jr_layout(size_t n_build, size_t n_probe) {
   L.p_a = L.b_meta + mb;
   L.p_b = L.p_a + cp;
   L.p_meta = L.p_b + (L.k2 > 1 ? cp : 0);
-  L.total = L.p_meta + mb;
+  L.max_giants = jr_max_giants(n_build, n_probe);
+  L.giant_off = L.p_meta + mb;
+  L.total = align_up(L.giant_off + jl_giant_bytes(L.max_giants, true), kWsAlign);
   return L;
 }
 // where a partitioned side ended up is a pure function of the sizes: no state is kept between the calls
@@ -1610,10 +1705,31 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
+  // partitions with a giant build OR probe side (join_common.hpp): left out by the fused kernel, listed, then built into
+  // scratch sub-tables (jl_giant_count / jl_giant_ids) and probed (jl_giant_probe) by all workgroups together
+  JlGiants giants{nullptr, 0u, ~0ull, ~0ull, 0u};
+  if (L.max_giants && !jl_no_giants()) {
+    giants.base = reinterpret_cast<unsigned *>(base + L.giant_off);
+    giants.max = L.max_giants;
+    giants.rows = jl_giant_rows(n_build);
+    giants.probe_rows = jl_giant_rows(n_probe);
+    giants.with_tables = 1u;
+    const hipError_t eg = fill_async(giants.base, 0, jl_giant_header_bytes(L.max_giants), s);
+    if (eg != hipSuccess) return static_cast<int>(eg);
+  }
+  const JlMatchArgs match{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt};
+  unsigned *status = reinterpret_cast<unsigned *>(base);
   hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
                      static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
-                     static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, reinterpret_cast<unsigned *>(base),
-                     JlMatchArgs{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt}, JlGiants{nullptr, 0u, ~0ull});
+                     static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, status, match, giants);
+  if (giants.max) {
+    const unsigned grid = static_cast<unsigned>(dev.cus) * (2048 / kJlGiantThreads);
+    hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
+                       static_cast<u32x2 *>(nullptr), jl_pos_bits(n_build), giants, status);
+    hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
+                       static_cast<u32x2 *>(nullptr), giants, ids, status);
+    hipLaunchKernelGGL(jl_giant_probe_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, match, jl_pos_bits(n_build), giants);
+  }
   return launch_status();
 }
 

@@ -169,7 +169,7 @@ def _check_grouped_join(build, probe):
                                   "1500 keys of one partition, 40 rows each", "two giants and 1200 keys of a third"])
 def test_join_build_with_giant_partitions(kind, n):
     """A partition far above its expected 2048 rows (hot keys) is counted and filled by all workgroups together
-    (join_lds.hip jl_giant_count / jl_giant_fill; from 2^18 build rows, giants above max(32768, n / 1024) rows)."""
+    (join_lds.hip jl_giant_count / jl_giant_ids; from 2^18 build rows, giants above max(32768, n / 1024) rows)."""
     rng = np.random.default_rng(23)
     build = po.gen_uniform_u32(n, 42, 0, n - 1)
     probe = po.gen_uniform_u32(1 << 18, 43, 0, n - 1)
@@ -328,6 +328,38 @@ def test_radix_join_matches_oracle(nb, npr, hi):
         for i in range(0, npr, 7):
             r = int(rid[i])
             assert np.array_equal(np.sort(ids[pos[i]: pos[i] + cnt[i]]).astype(np.uint64), bids[int(off[r]): int(off[r + 1])])
+
+
+@pytest.mark.parametrize("nb,npr", [(1 << 18, 1 << 18), (1 << 22, (1 << 21) + 9), (1 << 16, 1 << 20), (1 << 20, 3000)])
+@pytest.mark.parametrize("kind", ["hot build key", "hot probe key", "the same key hot on both sides", "hot keys that differ",
+                                  "every row of both sides one key"])
+def test_radix_join_with_giant_partitions(kind, nb, npr):
+    """partitions whose build OR probe side is far above the expected size are left out by the fused kernel and done by
+    all workgroups together: scratch sub-tables (jl_giant_count / jl_giant_ids), then jl_giant_probe"""
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(29)
+    ha = po.gen_uniform_u32(nb, 42, 0, nb - 1)
+    hb = po.gen_uniform_u32(npr, 43, 0, nb - 1)
+    if kind in ("hot build key", "the same key hot on both sides", "hot keys that differ"):
+        ha[rng.random(nb) < 0.5] = 4242
+    if kind in ("hot probe key", "the same key hot on both sides"):
+        hb[rng.random(npr) < 0.5] = 4242
+    if kind == "hot keys that differ":
+        hb[rng.random(npr) < 0.5] = 17
+    if kind == "every row of both sides one key":
+        if nb * npr > 1 << 41:
+            pytest.skip("2^42 matches and more: nothing to learn")
+        ha[:] = 9
+        hb[:] = 9
+    rid, pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.radix_join(_dev(ha), _dev(hb)))
+    assert np.array_equal(np.sort(rid), np.arange(npr, dtype=np.uint32))
+    assert np.array_equal(np.sort(ids), np.arange(nb, dtype=np.uint32))
+    assert np.array_equal(cnt, po.join_counts_fast(ha, hb).astype(np.uint32)[rid])
+    in_order = ha[ids]
+    assert np.count_nonzero(in_order[1:] != in_order[:-1]) + 1 == np.unique(ha).size  # every key's ids are one run
+    hit = cnt > 0
+    assert np.array_equal(in_order[pos[hit]], hb[rid[hit]])
+    assert np.array_equal(in_order[pos[hit] + cnt[hit] - 1], hb[rid[hit]])
 
 
 def test_radix_join_carries_caller_row_ids_and_agrees_with_the_probe_path():

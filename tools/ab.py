@@ -371,11 +371,13 @@ def graph(_):
 def launch_join(lg):
     n = 1 << (lg or 26)
     build, probe = ops.gen_uniform_u32(n, 42, 0, n - 1), ops.gen_uniform_u32(n, 43, 0, n - 1)
-    hot = os.environ.get("JOIN_HOT", "")  # build | probe: every other row of that side carries one key
+    hot = os.environ.get("JOIN_HOT", "")  # build | probe: every other row of that side carries one key; few: 1024 distinct build keys
     if hot == "build":
         build[::2] = 12345
     if hot == "probe":
         probe[::2] = 12345
+    if hot == "few":  # 1024 distinct build keys
+        build = bits32(u64(build) % 1024)
     plan = ops.HashJoin(n, n)
     for _i in range(5):
         plan.build(build)
