@@ -22,7 +22,8 @@
 //          neighbour crossed a 64-byte line for every eighth row: one more memory request); the all-ones
 //          field sends the row to the right-hand neighbour.  Partition from the high hash bits, linear
 //          probing inside the sub-table, outputs written coalesced in row order.
-// A partition may hold any number of rows (duplicates do not matter); it may hold at most DBHIP_JL_SUB_SLOTS
+// A partition may hold any number of rows (duplicates do not matter: one far above its expected size — a hot key — is
+// shared by all workgroups, see "giant partitions" below); it may hold at most DBHIP_JL_SUB_SLOTS
 // (3072) DISTINCT keys — with 2048 rows expected per partition (+-45 per sigma) and a mixing hash that takes keys
 // constructed against the hash; if it happens the build sets DBHIP_DEV_TABLE_FULL (the call fails loudly, there
 // is no second partitioning with another hash).

@@ -160,7 +160,9 @@ int dbhip_groupby_merge_u32(uint32_t groups, uint32_t max_private_tables, uint32
  * 0xFFFFFFFF is the empty-slot sentinel and must not occur as a key
  * (join/join_omnisci.cpp:52): a build row carrying it sets DBHIP_DEV_KEY_RANGE and is dropped, a probe row
  * carrying it gets 0/0.  The table lives in the workspace between build and probe; the
- * probe takes n_build again because the table geometry is a pure function of it.               */
+ * probe takes n_build again because the table geometry is a pure function of it.
+ * A key may repeat any number of times: the rows of a hot key are shared by all workgroups (from 2^18 build rows
+ * on; a build in which every other row carries one key takes 1.3-1.4 x the time of uniform keys).   */
 size_t dbhip_join_workspace_bytes(size_t n_build);
 int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
