@@ -256,6 +256,66 @@ def bench_join_radix(steps, warmup, log2n=26):
             "workload": f"HashJoin 2^{log2n} x 2^{log2n} uint32 keys as a radix join (results with row ids, partition order)"}
 
 
+def bench_crowded_keys(steps, uniform):
+    """The dwarfs on keys that crowd — the reference's generators are uniform, a caller's data need not be: the worst
+    shape found for each dwarf by tools/ab.py sort-shapes | groupby-skew | join-skew, next to the uniform time of the
+    same dwarf from this run (lane copies of the LDS histograms, ballot ranking where a wave sees a
+    crowd, a cross-wave sum before the LDS add, giant join partitions shared by all workgroups)."""
+    import torch
+    from dwarf_bench_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    out = {}
+
+    def med(fn):
+        fn()
+        ts = sorted(_event_times_us(fn, steps))
+        return ts[len(ts) // 2]
+
+    n = 1 << 24
+    spread = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    hot = torch.rand(n, device="cuda", generator=g) < 0.9
+    keys0 = torch.where(hot, torch.full_like(spread, 0x1E3779B9), spread)
+    keys = keys0.clone()
+    copy_us = med(lambda: keys.copy_(keys0))
+    for bits in (8, 4):
+        plan = ops.RadixSort(n, bits)
+
+        def run():
+            keys.copy_(keys0)
+            plan.launch(keys)
+
+        us = med(run) - copy_us
+        assert ops.workspace_status(plan.ws) == 0
+        base = uniform.get(f"sort_{bits}bit", {}).get("kernel_us")
+        out[f"sort_{bits}bit_90pct_one_value"] = {"rows": n, "kernel_us": us, "uniform_kernel_us": base,
+                                                  "over_uniform": us / base if base else None}
+    del spread, hot, keys0, keys
+    n = 1 << 26
+    vals = ops.gen_uniform_u32(n, 43, 1, 10000)
+    for groups in (1 << 15, 1 << 16):
+        one = torch.full((n,), groups // 3, dtype=torch.int32, device="cuda")
+        plan = ops.GroupBySum(n, groups)
+        us = med(lambda: plan.launch(one, vals))
+        plan.result()
+        entry = {"rows": n, "groups": groups, "kernel_us": us}
+        if groups == uniform.get("groupby", {}).get("groups"):
+            entry["uniform_kernel_us"] = uniform["groupby"]["kernel_us"]
+            entry["over_uniform"] = us / uniform["groupby"]["kernel_us"]
+        out[f"groupby_{groups}_groups_every_row_one_group"] = entry
+        del one, plan
+    del vals
+    torch.cuda.empty_cache()
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    build[::2] = 12345
+    plan = ops.HashJoin(n, n)
+    us = med(lambda: plan.build(build))
+    assert ops.workspace_status(plan.ws) == 0
+    base = uniform.get("join", {}).get("build_us")
+    out["join_build_every_other_row_one_key"] = {"rows": n, "build_us": us, "uniform_build_us": base,
+                                                 "over_uniform": us / base if base else None}
+    return out
+
+
 def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
     """Radix-partitioned hash join of 2^log2_total x 2^log2_total rows over all ranks (strong scaling: the total
     is fixed, every rank holds a contiguous 1/P shard of both key columns, generated in place)."""
@@ -741,6 +801,10 @@ def main():
                 dwarfs["pjoin_p1"] = bench_pjoin_native(3, 1, 30, None, 0, 1, local, solo=True)
                 torch.cuda.empty_cache()
                 dwarfs["pjoin_p1_torch_host"] = bench_pjoin(2, 1, 30, None)
+        if args.dwarf == "all" and not args.no_sweep:
+            torch.cuda.empty_cache()
+            dwarfs["crowded_keys"] = bench_crowded_keys(5, dwarfs)
+            torch.cuda.empty_cache()
         if not args.no_cpu:
             want = [w for w in ("sort", "groupby", "join") if args.dwarf in ("all", w)]
             for name, base in cpu_baselines_dwarfs(want).items():
