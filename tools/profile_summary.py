@@ -31,7 +31,7 @@ DWARFS = {
     "sort_4bit": (r"rs_\w+<4", r"rs_histogram", True),
     "groupby": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", True),
     # join: 4-B/lane reads and random 16-B gathers — widths the guide calls uncalibrated: raw counter, not doubled
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_build_kernel<false>", False),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_build_kernel<false>", False),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", False),
 }
 
@@ -61,11 +61,14 @@ CONFIGS = {
     "sort_2p24_8bit": (r"rs_\w+<8|rs_finalize", r"rs_histogram_kernel<8", r"rs_finalize_kernel"),
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
     "groupby_2p26_2p16": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", r"gb_reduce\w*kernel"),
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_build_kernel<false>"),
+    # (the two launches for giant partitions close a build; they find none on the bench's uniform keys)
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_giant_ids_kernel"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
-    # the radix join: both sides through the partitioner, then the fused build + probe launch
-    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_build_kernel<true>"),
+    # the radix join: both sides through the partitioner, then the fused build + probe launch (+ three for giants)
+    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>|jl_giant_\w+_kernel", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_giant_probe_kernel"),
 }
+# a kernel of ANOTHER configuration that shares kernels with this one: a call that meets it is not this configuration's
+FOREIGN = {"join_build": r"jl_build_kernel<true>|jl_giant_probe_kernel", "join_radix_2p26": r"jl_build_kernel<false>|jl_probe_kernel"}
 
 
 def read_trace(raw: Path):
@@ -86,7 +89,8 @@ def headline(raw: Path, matches_scan: float = 4.034e-4):
            "join_radix_2p26": 24 * N_JOIN}
     out = {}
     for name, (pat, first, last) in CONFIGS.items():
-        mine = [r for r in rows if re.search(pat, r[2])]
+        foreign = FOREIGN.get(name)
+        mine = [r for r in rows if re.search(pat, r[2]) or (foreign and re.search(foreign, r[2]))]
         if not mine:
             continue
         if name == "scan_2p28":  # the bench also scans 2^22 rows once for its result check: keep the 2^28 launches
@@ -101,6 +105,9 @@ def headline(raw: Path, matches_scan: float = 4.034e-4):
         # cut the chronological list into calls: [opening kernel .. closing kernel]
         calls, cur = [], None
         for r in mine:
+            if foreign and re.search(foreign, r[2]):
+                cur = None
+                continue
             if re.search(first, r[2]) and cur is None:
                 cur = []
             if cur is not None:
