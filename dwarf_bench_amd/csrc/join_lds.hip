@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
 //                   and adds the slice's count to that slot's counter — one memory-side atomic per slice and key, not per
 //                   row.  The workgroup that finishes a giant's LAST slice (a counter per giant) scans the slot counters:
 //                   first id position of every slot -> the table's position words and the slot cursors.
-//   jl_giant_ids   the slices are counted again the same way; per distinct key ONE returning add on the slot's cursor
+//   jl_giant_ids    the slices are counted again the same way; per distinct key ONE returning add on the slot's cursor
 //                   reserves the slice's share of the key's id range, then every row takes its place inside the share
 //                   from an LDS cursor and stores its row id.
 // Lanes of a wave that meet on one LDS counter (that is what a hot key is) are added by one lane: jl_take.
@@ -1205,10 +1205,17 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
   }
 }
 
+__device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out);
+// (radix join, match.spairs != nullptr: the same launch then runs the listed partitions' PROBE rows against their scratch
+//  sub-tables, in slices of kJlSlice rows over all workgroups — they need the tables' position words, which
+//  jl_giant_count finished, not the ids; one 8-byte gather per row, a hot key's slot one cache line for everybody;
+//  results at the row's place in the probe side's partition order, like the fused kernel's)
 __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32x2 *__restrict__ rows,
                                                                         const unsigned long long *__restrict__ starts,
                                                                         u32x2 *table, JlGiants giants,
-                                                                        unsigned *__restrict__ ids, unsigned *status) {
+                                                                        unsigned *__restrict__ ids, unsigned *status,
+                                                                        JlMatchArgs match, unsigned pos_bits) {
   __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
   __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave];
   const unsigned tid = threadIdx.x;
@@ -1262,6 +1269,27 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
     }
     __syncthreads();  // lk / lc are reused by the next slice
   }
+  if (match.spairs == nullptr) return;
+  __syncthreads();
+  const unsigned pitems = jl_giant_slices(giants, match.sstarts, s_first, s_wsum, &ng);
+  const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
+  const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
+  for (unsigned item = blockIdx.x; item < pitems; item += gridDim.x) {
+    const unsigned g = jl_giant_of(s_first, ng, item);
+    const unsigned part = giants.part()[g];
+    const size_t slo = match.sstarts[part], shi = match.sstarts[part + 1];
+    const size_t a = slo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
+    const size_t b = a + kJlSlice < shi ? a + kJlSlice : shi;
+    const u32x2 *sub = giants.scratch_table(g);
+    for (size_t j = a + tid; j < b; j += kJlGiantThreads) {
+      const u32x2 row = match.spairs[j];
+      unsigned pos, cnt;
+      jl_probe_sub(row.x, fmix32(row.x), sub, pos_bits, pos_mask, cnt_esc, &pos, &cnt);
+      match.out_rid[j] = row.y;
+      match.out_pos[j] = pos;
+      match.out_cnt[j] = cnt;
+    }
+  }
 }
 
 // one probe row: slot {key, first position | count field} by linear probing inside the key's sub-table
@@ -1291,34 +1319,6 @@ __device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32
   }
   *pos_out = pos;
   *cnt_out = cnt;
-}
-
-// radix join: the probe rows of the listed partitions against their scratch sub-tables — slices of kJlSlice rows over
-// all workgroups, one 8-byte gather per row (a hot key's slot is one cache line for everybody); results at the row's
-// place in the probe side's partition order, like the fused kernel's
-__global__ __launch_bounds__(kJlGiantThreads) void jl_giant_probe_kernel(JlMatchArgs match, unsigned pos_bits, JlGiants giants) {
-  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave];
-  const unsigned tid = threadIdx.x;
-  unsigned ng;
-  const unsigned items = jl_giant_slices(giants, match.sstarts, s_first, s_wsum, &ng);
-  const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
-  const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
-  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
-    const unsigned g = jl_giant_of(s_first, ng, item);
-    const unsigned part = giants.part()[g];
-    const size_t slo = match.sstarts[part], shi = match.sstarts[part + 1];
-    const size_t a = slo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
-    const size_t b = a + kJlSlice < shi ? a + kJlSlice : shi;
-    const u32x2 *sub = giants.scratch_table(g);
-    for (size_t j = a + tid; j < b; j += kJlGiantThreads) {
-      const u32x2 row = match.spairs[j];
-      unsigned pos, cnt;
-      jl_probe_sub(row.x, fmix32(row.x), sub, pos_bits, pos_mask, cnt_esc, &pos, &cnt);
-      match.out_rid[j] = row.y;
-      match.out_pos[j] = pos;
-      match.out_cnt[j] = cnt;
-    }
-  }
 }
 
 #ifndef DBHIP_JL_PROBE_ROWS
@@ -1634,7 +1634,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
     hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
                        p.starts, p.table, jl_pos_bits(n), giants, p.status);
     hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
-                       p.starts, p.table, giants, ids, p.status);
+                       p.starts, p.table, giants, ids, p.status, JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, 0u);
   }
   return launch_status();
 }
@@ -1707,7 +1707,7 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
   // partitions with a giant build OR probe side (join_common.hpp): left out by the fused kernel, listed, then built into
-  // scratch sub-tables (jl_giant_count / jl_giant_ids) and probed (jl_giant_probe) by all workgroups together
+  // scratch sub-tables (jl_giant_count / jl_giant_ids) and probed (second half of jl_giant_ids) by all workgroups together
   JlGiants giants{nullptr, 0u, ~0ull, ~0ull, 0u};
   if (L.max_giants && !jl_no_giants()) {
     giants.base = reinterpret_cast<unsigned *>(base + L.giant_off);
@@ -1728,8 +1728,7 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
     hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
                        static_cast<u32x2 *>(nullptr), jl_pos_bits(n_build), giants, status);
     hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
-                       static_cast<u32x2 *>(nullptr), giants, ids, status);
-    hipLaunchKernelGGL(jl_giant_probe_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, match, jl_pos_bits(n_build), giants);
+                       static_cast<u32x2 *>(nullptr), giants, ids, status, match, jl_pos_bits(n_build));
   }
   return launch_status();
 }

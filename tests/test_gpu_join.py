@@ -335,7 +335,7 @@ def test_radix_join_matches_oracle(nb, npr, hi):
                                   "every row of both sides one key"])
 def test_radix_join_with_giant_partitions(kind, nb, npr):
     """partitions whose build OR probe side is far above the expected size are left out by the fused kernel and done by
-    all workgroups together: scratch sub-tables (jl_giant_count / jl_giant_ids), then jl_giant_probe"""
+    all workgroups together: scratch sub-tables (jl_giant_count / jl_giant_ids), their probe rows in jl_giant_ids' second half"""
     from dwarf_bench_amd import ops
     rng = np.random.default_rng(29)
     ha = po.gen_uniform_u32(nb, 42, 0, nb - 1)

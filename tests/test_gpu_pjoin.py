@@ -80,7 +80,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, key_hi, q):
+def _worker(rank, world, port, n, key_hi, q, hot=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -91,6 +91,9 @@ def _worker(rank, world, port, n, key_hi, q):
         lo, hi = rank * per, (n if rank == world - 1 else (rank + 1) * per)
         build = ops.gen_uniform_u32(hi - lo, 42, 1, key_hi, first_index=lo)
         probe = ops.gen_uniform_u32(hi - lo, 43, 1, key_hi, first_index=lo)
+        if hot:  # (shards start at even rows: the same rows as [::2] / [::128] of the whole columns)
+            build[::2] = 77
+            probe[::128] = 77
         res = pjoin.partitioned_join(build, probe, lo, lo)  # HipBackend
         u = lambda t: t.cpu().numpy().view(np.uint32).copy()
         q.put((rank, u(res.probe_row_ids), u(res.pos), u(res.cnt), u(res.build_row_ids)))
@@ -127,6 +130,38 @@ def test_ranks_sharing_one_gpu(world, n, key_hi):
             hit = cnt > 0
             assert np.all(build_all[ids[pos[hit]]] == probe_all[rid[hit]])
         assert np.array_equal(got, want)
+
+
+def test_ranks_sharing_one_gpu_with_a_hot_key():
+    """every other build row carries one key: all of them travel to ONE rank, whose local radix join finds them in one
+    giant partition (join_lds.hip jl_giant_*); counts per global probe row and the ids' ends against numpy"""
+    import torch.multiprocessing as mp
+    world, n, key_hi = 2, 1 << 21, (1 << 21) - 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, key_hi, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    build_all = po.gen_uniform_u32(n, 42, 1, key_hi)
+    probe_all = po.gen_uniform_u32(n, 43, 1, key_hi)
+    build_all[::2] = 77
+    probe_all[::128] = 77
+    want = po.join_counts_fast(build_all, probe_all)
+    got = np.zeros(n, dtype=np.uint64)
+    rows = 0
+    for _, rid, pos, cnt, ids in outs:
+        got[rid] = cnt
+        rows += rid.size
+        hit = cnt > 0
+        assert np.all(build_all[ids[pos[hit]]] == probe_all[rid[hit]])
+        assert np.all(build_all[ids[pos[hit] + cnt[hit] - 1]] == probe_all[rid[hit]])
+    assert rows == n and np.array_equal(got, want)
+    assert max(o[4].size for o in outs) > n // 2  # the hot key's rows all went to one rank
 
 
 @pytest.mark.parametrize("n,direct", [(1000, False), (1000, True), (300007, False), (1 << 22, True), (1 << 22, False)])
