@@ -127,12 +127,25 @@ inline RsGeometry rs_geometry(size_t n, int bits) {
   // 4-bit digits: half as many, twice as long chunks (2^24 keys: 378 -> 363 us; 8-bit digits: no difference)
   const size_t target = bits == 4 ? kRsTargetChunks / 2 : kRsTargetChunks;
   g.tiles = (n + kRsTile - 1) / kRsTile;
-  g.tiles_per_chunk = (g.tiles + target - 1) / target;
-  if (g.tiles_per_chunk == 0) g.tiles_per_chunk = 1;
+  // Every chunk holds the same number of tiles, q or q + 1 with q = tiles / target — whichever brings the number of
+  // chunks closer to the target (as a ratio): q while tiles < target * sqrt(q (q + 1)).  (Until late in round 3 it was
+  // always the ceiling: one key more than 2^24 meant 1025 chunks of two tiles instead of 2049 of one — 231 us against
+  // 200; dealing the tiles out as evenly as they go, with chunks of q and of q + 1 tiles in one pass, removed that
+  // step and lost 10-15 % at sizes in between.)  At most 1.42 * target chunks.
+  // 4-bit digits keep the ceiling: their chunks are twice as long and 1025 of them are three rounds of workgroups where
+  // 1024 are two (same box, old rule -> this one: 2^26 + 1 keys 1431 -> 1537 us, 2^27 + 12345 keys 2914 -> 3294; with
+  // 8-bit digits every size measured got faster or stayed: 2^24 + 1 keys 234 -> 201, 2^24 + 2^20 257 -> 213, 2^25 + 1
+  // 464 -> 428, 2^26 + 1 1025 -> 991, 2^27 + 12345 2003 -> 1959).
+  const size_t q = g.tiles / target;
+  g.tiles_per_chunk = q == 0 ? 1 : (bits != 4 && g.tiles * g.tiles < q * (q + 1) * target * target ? q : q + 1);
+  if (g.tiles == q * target && q != 0) g.tiles_per_chunk = q;
   g.chunks = (g.tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
   if (g.chunks == 0) g.chunks = 1;
   return g;
 }
+// the rows of the count matrix counts[digit][chunk] are padded to four chunks: a histogram workgroup's counts of four
+// consecutive chunks are ONE aligned 16-byte store whatever the number of chunks (the padding stays zero)
+__host__ __device__ __forceinline__ size_t rs_row_stride(size_t num_chunks) { return (num_chunks + 3) & ~static_cast<size_t>(3); }
 
 // lanes of the wave whose digit equals mine: BITS ballots (no match instruction on CDNA).  Per bit and 32-lane
 // half: sel = bit ? ballot : ~ballot = ~(ballot ^ (bit ? ~0 : 0)), one v_xnor_b32 on the sign-extended bit
@@ -285,9 +298,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
       s_byte0[threadIdx.x] += c;
     }
     if (BITS == 8) {
-      const bool vec = kCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;
+      const bool vec = kCpw == 4;  // (rows are padded to four chunks)
       if (threadIdx.x < kRadix) {
-        unsigned *row = counts0 + static_cast<size_t>(threadIdx.x) * num_chunks + chunk0;
+        unsigned *row = counts0 + static_cast<size_t>(threadIdx.x) * rs_row_stride(num_chunks) + chunk0;
         if (vec) {
           *reinterpret_cast<u32x4 *>(row) = u32x4{mine[0], mine[1 % kCpw], mine[2 % kCpw], mine[3 % kCpw]};
         } else {
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const unsigned
         unsigned c = 0;
 #pragma unroll
         for (int hi4 = 0; hi4 < 16; ++hi4) c += s_chunks[0][hi4 * 16 + threadIdx.x];
-        counts0[static_cast<size_t>(threadIdx.x) * num_chunks + chunk0] = c;
+        counts0[static_cast<size_t>(threadIdx.x) * rs_row_stride(num_chunks) + chunk0] = c;
       }
     }
     __syncthreads();
@@ -409,9 +422,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_hist_kernel(const unsigne
     for (int k = 0; k < kCopies; ++k) sum += s_hist[c][k * kStride + d];
     return sum;
   };
-  const bool vec = kRsHistCpw == 4 && chunk0 + 4 <= num_chunks && (num_chunks & 3) == 0;  // 16-byte aligned row pieces
+  const bool vec = kRsHistCpw == 4;  // 16-byte aligned row pieces (rows are padded to four chunks)
   for (int d = threadIdx.x; d < kRadix; d += kRsThreads) {
-    unsigned *row = counts + static_cast<size_t>(d) * num_chunks + chunk0;
+    unsigned *row = counts + static_cast<size_t>(d) * rs_row_stride(num_chunks) + chunk0;
     if (vec) {
       *reinterpret_cast<u32x4 *>(row) = u32x4{count_of(0, d), count_of(1 % kRsHistCpw, d), count_of(2 % kRsHistCpw, d), count_of(3 % kRsHistCpw, d)};
     } else {
@@ -429,11 +442,11 @@ __global__ __launch_bounds__(kRsThreads) void rs_chunk_scan_kernel(int pass, con
   // wave scan of the thread sums, wave sums through LDS (a loop of 512-chunk rounds with three barriers each took 5 us
   // for 2048 chunks, most of it barrier and LDS latency)
   constexpr unsigned kMaxPer = 8;
-  static_assert(kRsTargetChunks <= static_cast<size_t>(kMaxPer) * kRsThreads, "chunks per scan workgroup");
+  static_assert(kRsTargetChunks * 3 / 2 <= static_cast<size_t>(kMaxPer) * kRsThreads, "chunks per scan workgroup (rs_geometry: at most 1.42 x the target)");
   __shared__ unsigned s_wsum[kRsWaves];
   if (hdr->pass[pass].skip) return;
   const unsigned d = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  unsigned *row = counts + static_cast<size_t>(d) * num_chunks;
+  unsigned *row = counts + static_cast<size_t>(d) * rs_row_stride(num_chunks);
   const unsigned per = static_cast<unsigned>((num_chunks + kRsThreads - 1) / kRsThreads);
   const size_t first = static_cast<size_t>(tid) * per;
   unsigned v[kMaxPer], mine = 0;
@@ -699,10 +712,10 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
   if (tid < kRadix) {
     if (bases) {
       running = bases[pass * kRsMaxRadix + tid];
-      const unsigned *row = offsets + static_cast<size_t>(tid) * num_chunks;
+      const unsigned *row = offsets + static_cast<size_t>(tid) * rs_row_stride(num_chunks);
       for (size_t c = 0; c < chunk; ++c) running += row[c];
     } else {
-      running = offsets[static_cast<size_t>(tid) * num_chunks + chunk];
+      running = offsets[static_cast<size_t>(tid) * rs_row_stride(num_chunks) + chunk];
     }
   }
 
@@ -915,7 +928,7 @@ extern "C" size_t dbhip_radix_sort_workspace_bytes(size_t n, int radix_bits) {
   if (radix_bits != 4 && radix_bits != 8) return 0;
   const RsGeometry g = rs_geometry(n, radix_bits);
   const size_t radix = static_cast<size_t>(1) << radix_bits;
-  return align_up(kRsCountsOff + sizeof(unsigned) * radix * g.chunks, kWsAlign);
+  return align_up(kRsCountsOff + sizeof(unsigned) * radix * rs_row_stride(g.chunks), kWsAlign);
 }
 
 extern "C" int dbhip_radix_sort_rank_mode(void) {

@@ -136,6 +136,20 @@ def test_sort_2_24_baseline_config(bits):
     assert np.array_equal(keys.cpu().numpy().view(np.uint32), po.sort_u32(host))
 
 
+@pytest.mark.parametrize("bits", [8, 4])
+@pytest.mark.parametrize("n", [(1 << 24) + 1, 2896 * 8192 - 3, 2897 * 8192 + 5, (1 << 25) + 8193, 1025 * 8192 + 1])
+def test_sort_sizes_around_the_chunk_geometry_steps(n, bits):
+    """the number of tiles per chunk steps where tiles / target passes sqrt(q (q + 1)) (8-bit) or an integer (4-bit):
+    radix.hip rs_geometry; the count matrix's rows are padded to four chunks.  Against torch.sort of the same bits."""
+    from dwarf_bench_amd import ops
+    keys = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+    exp = torch.sort(keys.to(torch.int64) & 0xFFFFFFFF).values
+    plan = ops.RadixSort(n, bits)
+    plan.launch(keys)
+    assert ops.workspace_status(plan.ws) == 0
+    assert torch.equal(keys.to(torch.int64) & 0xFFFFFFFF, exp)
+
+
 def test_large_input_properties_2_30():
     """2^30 + 3 keys (4 GiB): sorted, same multiset (order-independent checksums), 64 tiles per chunk"""
     from dwarf_bench_amd import ops

@@ -15,6 +15,7 @@ the contract numbers come from bench.py.
   sort-shapes [lg] 2^lg keys of eight distributions (few distinct values, sorted, reversed, skewed ...; median of 5)
   join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
   join-skew [lg]  the same over key shapes (hot keys, strided keys, sorted, few distinct keys; median of 3)
+  size-sweep      every dwarf at sizes next to and between powers of two, 2^13 .. 2^26 (geometry cliffs)
   partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
   reduce          2^28-row reduce (median of 15; DBHIP_RED_WGS)
   xscan [lg]      exclusive scan of 2^lg uint32, aligned (one launch) and offset by one element (three launches)
@@ -266,6 +267,8 @@ def join_skew(lg):
         yield "keys are multiples of 1024", bits32(u64(uni_b) % 65536 * 1024), bits32(u64(uni_p) % 65536 * 1024)
         yield "sorted", bits32(torch.sort(u64(uni_b)).values), bits32(torch.sort(u64(uni_p)).values)
         yield "1024 distinct keys on the build side", bits32(u64(uni_b) % 1024), uni_p
+        yield "both sides in [1, 10000] (reference)", ops.gen_uniform_u32(n, 42, 1, 10000), ops.gen_uniform_u32(n, 43, 1, 10000)
+        yield "both sides in [0, 2^15)", bits32(u64(uni_b) % 32768), bits32(u64(uni_p) % 32768)
 
     for kind, build, probe in shapes():
         plan = ops.HashJoin(n, n)
@@ -288,6 +291,42 @@ def join_skew(lg):
         ok = int(rj.cnt.to(torch.int64).sum()) == total == _matches(build, probe)
         del rj
         print(f"{TAG:16s} 2^{lg} {kind:38s}: build {b:9.1f} probe {p:9.1f} | radix join {r:9.1f} us  matches {'equal' if ok else 'DIFFER'}", flush=True)
+
+
+def size_sweep(_):
+    """every dwarf over sizes next to and between powers of two (median of 5): a row that costs much more per element
+    than its neighbours is a geometry cliff"""
+    def line(name, n, us):
+        print(f"{TAG:12s} {name:28s} n={n:10d}: {us:9.1f} us  {us * 1e3 / max(n, 1):8.3f} ns/row", flush=True)
+
+    for lg in (13, 14, 16, 18, 20, 22, 24, 26):
+        for n in ((1 << lg) - 1, 1 << lg, (1 << lg) + 1, 3 << (lg - 1)):
+            src = ops.gen_uniform_u32(n, 42, 1, 10000)
+            plan = ops.CopyIfLt(n)
+            line("scan x<5", n, median(times(lambda: plan.launch(src, 5), 5)))
+            line("scan x<5001 dense", n, median(times(lambda: plan.launch(src, 5001, dense=True), 5)))
+            keys0 = ops.gen_uniform_u32(n, 42, 0, 2**32 - 1)
+            keys = keys0.clone()
+            cp = median(times(lambda: keys.copy_(keys0), 5))
+            for bits in (8, 4):
+                sp = ops.RadixSort(n, bits)
+
+                def run():
+                    keys.copy_(keys0)
+                    sp.launch(keys)
+
+                line(f"sort {bits}-bit", n, median(times(run, 5)) - cp)
+            for groups in (1000, 32768, 32769, 65536, 65537):
+                gk = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+                gp = ops.GroupBySum(n, groups)
+                line(f"groupby G={groups}", n, median(times(lambda: gp.launch(gk, src), 5)))
+                del gk, gp
+            b = ops.gen_uniform_u32(n, 42, 0, n - 1)
+            jp = ops.HashJoin(n, n)
+            line("join build", n, median(times(lambda: jp.build(b), 3)))
+            line("join probe", n, median(times(lambda: jp.probe(keys0), 3)))
+            del jp, b, src, plan, keys0, keys
+            torch.cuda.empty_cache()
 
 
 def partition(_):
@@ -424,7 +463,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "partition": partition,
+MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
