@@ -94,16 +94,23 @@ struct JlLayout {
 
 inline JlLayout jl_layout(size_t n) {
   JlLayout L;
+  // parts = ceil(n / kJlRowsPerPart) rounded up to a multiple of the level-1 fan-out k2 (a power of two: level 1 takes
+  // the low bits of the partition id, level 0 the rest — any number k1 <= 1024 of buckets; the partition id itself is a
+  // multiply-shift of the hash and takes any range).  Until late in round 3 parts was the next POWER of two: one row
+  // more than 2^26 meant 65536 half-empty partitions — build 1245 us against 1029, twice the table.
+  size_t want = (n + kJlRowsPerPart - 1) / kJlRowsPerPart;
+  if (want == 0) want = 1;
+  if (want > (static_cast<size_t>(1) << 20)) want = static_cast<size_t>(1) << 20;  // 2^20 partitions at most
   unsigned lg = 0;
-  while ((static_cast<size_t>(kJlRowsPerPart) << lg) < n && lg < 20) ++lg;  // 2^20 partitions at most
-  L.parts = 1u << lg;
-  if (L.parts <= 1024) {  // one scatter level handles up to 1024 buckets
+  while ((static_cast<size_t>(1) << lg) < want) ++lg;
+  if (want <= 1024) {  // one scatter level handles up to 1024 buckets
     L.log2_k2 = 0;
   } else {
     L.log2_k2 = (lg + DBHIP_JL_K2_BIAS) / 2;  // split of the partition bits between the two scatter levels
   }
   L.k2 = 1u << L.log2_k2;
-  L.k1 = L.parts / L.k2;
+  L.k1 = static_cast<unsigned>((want + L.k2 - 1) / L.k2);
+  L.parts = L.k1 * L.k2;
   const size_t col = align_up((n ? n : 1) * sizeof(unsigned), kWsAlign);
   L.table_off = kWsHeader;
   // 8-byte slots {key, first id position} + one sentinel slot after the last sub-table

@@ -5,7 +5,7 @@
 // Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
 // — three per build row — and three 4-byte gathers per probe row (53 G/s).  LDS atomics run at
 // > 800 G/s.  So:
-//   build  1. partition the build column into K = n/4096 partitions by the HIGH bits of the mixed hash,
+//   build  1. partition the build column into K = ceil(n / 2048) partitions (join_common.hpp jl_layout) by the mixed hash,
 //             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
 //             one global reservation per bucket per 4096-key tile, runs of (key, row id) pairs written
 //             contiguously);

@@ -138,9 +138,10 @@ def _fmix32(h):
 def _keys_of_partition(n_build, partition, how_many):
     """distinct keys that the build of n_build rows puts into one partition (join_lds.hip jl_pid: the high bits of
     fmix32(key) * parts; parts as join_common.hpp jl_layout has them)"""
-    parts = 1
-    while 2048 * parts < n_build and parts < (1 << 20):
-        parts *= 2
+    want = min(max(1, -(-n_build // 2048)), 1 << 20)
+    lg = (want - 1).bit_length()
+    k2 = 1 if want <= 1024 else 1 << (lg // 2)
+    parts = -(-want // k2) * k2
     cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
     mine = cand[(_fmix32(cand) * parts) >> 32 == partition][:how_many]
     assert mine.size == how_many
