@@ -117,6 +117,9 @@ constexpr unsigned kJlFusedThreads = 1024;
 #define DBHIP_JL_FUSED_MAX_PARTS 32768
 #endif
 constexpr unsigned kJlFusedMaxParts = DBHIP_JL_FUSED_MAX_PARTS;  // 0 disables the fused histogram (A/B timing)
+// two 16-bit counters per LDS word (jl_hist_fused16_kernel): as many partitions as the CU's 160 KiB hold — 2^27 rows
+// and a quarter more (a rank of the 8-GPU join receives 2^27 rows +- a few thousand: 65537+ partitions)
+constexpr unsigned kJlFused16MaxParts = 80 * 1024;
 
 __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const unsigned *__restrict__ keys, size_t n,
                                                                         unsigned parts, unsigned *__restrict__ wgcnt) {
@@ -1516,11 +1519,11 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   // output region, written only later by the level-1 scatter)
   // (8192..32768 partitions = 2^24..2^26 rows: level below it the two plain histograms are as fast, 2^22 rows: 77 vs 80 us)
   const bool fused = k2 > 1 && parts >= 8192 && parts <= kJlFusedMaxParts && fused_scratch != nullptr;
-  // 32768 < parts <= 65536 (2^27-row shards): the same with two 16-bit counters per LDS word (jl_hist_fused16_kernel)
+  // 32768 < parts <= 81920 (2^27-row shards and a quarter more): the same with two 16-bit counters per LDS word (jl_hist_fused16_kernel)
 #ifdef DBHIP_JL_NO_FUSED16  // A/B knob: the two plain histograms for these sizes, as in round 2
   const bool fused16 = false;
 #else
-  const bool fused16 = !fused && k2 > 1 && kJlFusedMaxParts != 0 && parts > kJlFusedMaxParts && parts <= 2 * kJlFusedMaxParts &&
+  const bool fused16 = !fused && k2 > 1 && kJlFusedMaxParts != 0 && parts > kJlFusedMaxParts && parts <= kJlFused16MaxParts &&
                        fused_scratch != nullptr;
 #endif
   if (fused16) {

@@ -209,6 +209,27 @@ def test_a_giant_partition_with_too_many_keys_is_flagged():
         plan.result()
 
 
+def test_join_a_few_rows_above_2_27_through_the_packed_histogram():
+    """what a rank of the 8-GPU join of 2^30 rows receives: 2^27 rows and a few thousand — 65792 partitions, still one
+    read of the keys for both histograms (two 16-bit counters per LDS word, up to 81920 partitions).  Counts per probe
+    row against a binary search in the sorted build column, ids a permutation whose ranges hold the probe's key."""
+    from dwarf_bench_amd import ops
+    n, m = (1 << 27) + 4097, 1 << 20
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(m, 43, 0, n - 1)
+    pos, cnt, ids = ops.hash_join(build, probe)
+    sb = torch.sort(build.to(torch.int64) & 0xFFFFFFFF).values
+    pk = probe.to(torch.int64) & 0xFFFFFFFF
+    want = torch.searchsorted(sb, pk, right=True) - torch.searchsorted(sb, pk, right=False)
+    del sb
+    assert torch.equal(cnt.to(torch.int64), want)
+    assert int(ids.to(torch.int64).sum().item()) == n * (n - 1) // 2
+    hit = cnt > 0
+    p, c = pos[hit].to(torch.int64), cnt[hit].to(torch.int64)
+    assert torch.equal(build[ids[p].to(torch.int64)], probe[hit])
+    assert torch.equal(build[ids[p + c - 1].to(torch.int64)], probe[hit])
+
+
 def test_ujoin_reference_fixture_shape(golden_dir):
     """unique-key payload join vs seq_join (join_helpers.hpp:86-104) as a multiset of rows (join.cpp:133)."""
     from dwarf_bench_amd import ops
