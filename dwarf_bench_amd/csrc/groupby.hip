@@ -225,7 +225,44 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
   // across the wave and added once (one key in all rows: 107-114 us; the test on uniform keys: nothing measurable; with
   // the test on tables of 16 copies, or crowds from 8 lanes: 92 -> 104 us, the wave sum costs more than the queue).
   const bool crowd_guard = !PACKED && geo.replicas <= 2;
+  unsigned crowd_misses = 0, crowd_tick = 0;  // steps in a row that found no crowd; steps since
   auto add_step = [&](size_t base, const u32x4 (&k)[kGbVecPerIter], const u32x4 (&v)[kGbVecPerIter]) {
+    // The question is asked of a step's FIRST row of keys — a hot or clustered key shows in every row alike — and only
+    // of every fourth step once four steps in a row have said no; a step that finds a crowd there asks it of each of its
+    // eight rows.  Asked of every row it cost the multi-range tables, whose workgroups walk every row
+    // of the columns with four or five instructions each, half their speed on uniform keys (2^24 rows into 100000
+    // groups: 57 -> 87 us); once per step still 20-30 % with four and eight ranges.
+    bool step_guard = false;
+    if (crowd_guard && (crowd_misses < 4 || (++crowd_tick & 3u) == 0)) {  // (uniform; every lane of the wave is here)
+      const unsigned rel0 = k[0].x - lo;
+      const bool in0 = rel0 < span;
+      const unsigned long long act = __ballot(in0);
+      const unsigned first = __builtin_amdgcn_readlane(rel0, act ? __builtin_ctzll(act) : 0);
+      step_guard = __builtin_popcountll(__ballot(in0 && rel0 == first)) >= kGbCrowd;
+      crowd_misses = step_guard ? 0u : crowd_misses + 1u;
+    }
+    if (!step_guard) {  // (uniform) the step as it always was: straight-line code, eight independent LDS adds
+#pragma unroll
+      for (int u = 0; u < kGbVecPerIter; ++u) {
+        const unsigned kk[4] = {k[u].x, k[u].y, k[u].z, k[u].w};
+        const unsigned vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const bool live = base + static_cast<size_t>(u) * THREADS + tid < n4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned rel = kk[c] - lo;
+          if (PACKED) {
+            if (rel < span) add_packed(kk[c], rel, vv[c]);
+          } else if (rel < span) {
+            atomicAdd(&s_table[rep_off + rel], vv[c]);
+          }
+          bad_key |= live && kk[c] >= groups;
+        }
+      }
+      return;
+    }
+    // a step with a crowd in its first row (never PACKED): every row sums its crowd across the wave and adds it once
+    // (with the question inside the loop above — one branch per row, never taken — the multi-range tables lost 20-30 %
+    //  on uniform keys however rarely the question was asked: the eight adds of a step were no longer issued together)
 #pragma unroll
     for (int u = 0; u < kGbVecPerIter; ++u) {
       const unsigned kk[4] = {k[u].x, k[u].y, k[u].z, k[u].w};
@@ -235,24 +272,18 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
       for (int c = 0; c < 4; ++c) {
         const unsigned rel = kk[c] - lo;
         bad_key |= live && kk[c] >= groups;
-        if (PACKED) {
-          if (rel < span) add_packed(kk[c], rel, vv[c]);
-          continue;
-        }
         const bool in = rel < span;
-        if (crowd_guard) {  // (uniform; every lane of the wave is here: the loop around add_step is uniform)
-          const unsigned long long act = __ballot(in);
-          const unsigned first = __builtin_amdgcn_readlane(rel, act ? __builtin_ctzll(act) : 0);
-          const bool same = in && rel == first;
-          const unsigned long long crowd = __ballot(same);
-          if (__builtin_popcountll(crowd) >= kGbCrowd) {
-            const unsigned sum = wave_reduce_add(same ? vv[c] : 0u);
-            if ((tid & (kWave - 1)) == static_cast<unsigned>(__builtin_ctzll(crowd))) atomicAdd(&s_table[rep_off + first], sum);
-            if (in && !same) atomicAdd(&s_table[rep_off + rel], vv[c]);
-            continue;
-          }
+        const unsigned long long act = __ballot(in);
+        const unsigned first = __builtin_amdgcn_readlane(rel, act ? __builtin_ctzll(act) : 0);
+        const bool same = in && rel == first;
+        const unsigned long long crowd = __ballot(same);
+        if (__builtin_popcountll(crowd) >= kGbCrowd) {
+          const unsigned sum = wave_reduce_add(same ? vv[c] : 0u);
+          if ((tid & (kWave - 1)) == static_cast<unsigned>(__builtin_ctzll(crowd))) atomicAdd(&s_table[rep_off + first], sum);
+          if (in && !same) atomicAdd(&s_table[rep_off + rel], vv[c]);
+        } else if (in) {
+          atomicAdd(&s_table[rep_off + rel], vv[c]);
         }
-        if (in) atomicAdd(&s_table[rep_off + rel], vv[c]);
       }
     }
   };
@@ -656,8 +687,13 @@ extern "C" int dbhip_groupby_sum_u32(const uint32_t *keys, const uint32_t *vals,
                                      uint32_t groups, uint32_t *out, void *workspace,
                                      size_t workspace_bytes, dbhip_stream_t stream) {
   if (groups && !out) return DBHIP_EINVAL;
-  const int rc = gb_partial(keys, vals, n, groups, 0, workspace, workspace_bytes, stream);
-  return rc != 0 ? rc : gb_merge(groups, 0, out, workspace, stream);
+  // Short columns get as many private tables as they have 8192-row steps for (a workgroup's step: 1024 lanes x two
+  // 16-byte loads per column), not one per CU: every table is cleared, written out and read back whatever it received —
+  // 2^13 rows into 32768 groups took 31 us, 256 tables of 128 KiB for one step's worth of rows.
+  const size_t steps = (n + 8191) / 8192;
+  const uint32_t tables = steps >= 256 ? 0u : static_cast<uint32_t>(steps ? steps : 1);
+  const int rc = gb_partial(keys, vals, n, groups, tables, workspace, workspace_bytes, stream);
+  return rc != 0 ? rc : gb_merge(groups, tables, out, workspace, stream);
 }
 
 // the two phases separately (GroupByLocal reports them separately, groupby/groupby_local.cpp:115-119)
