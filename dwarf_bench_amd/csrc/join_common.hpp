@@ -92,13 +92,22 @@ struct JlLayout {
   size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, giant_off, total;
 };
 
-inline JlLayout jl_layout(size_t n) {
+// The radix join's fused build + probe kernel likes its partitions emptier than the build kernel does (2^26 x 2^26, rows
+// per partition / fused kernel / whole radix join: 2048 / 908 us / 2103 us, 1920 / 798 / 2024, 1792 / 779 / 2006,
+// 1536 / 782 / 2013; the build that publishes its tables gets slower instead: 1053 -> 1065 -> 1100 us)
+#ifndef DBHIP_JR_ROWS_PER_PART
+#define DBHIP_JR_ROWS_PER_PART 1792
+#endif
+constexpr unsigned kJrRowsPerPart = DBHIP_JR_ROWS_PER_PART;
+static_assert(kJrRowsPerPart <= kJlRowsPerPart, "the build kernel caches kJlRowsPerPart + 1/8 rows of a partition");
+
+inline JlLayout jl_layout(size_t n, size_t rows_per_part = kJlRowsPerPart) {
   JlLayout L;
   // parts = ceil(n / kJlRowsPerPart) rounded up to a multiple of the level-1 fan-out k2 (a power of two: level 1 takes
   // the low bits of the partition id, level 0 the rest — any number k1 <= 1024 of buckets; the partition id itself is a
   // multiply-shift of the hash and takes any range).  Until late in round 3 parts was the next POWER of two: one row
   // more than 2^26 meant 65536 half-empty partitions — build 1245 us against 1029, twice the table.
-  size_t want = (n + kJlRowsPerPart - 1) / kJlRowsPerPart;
+  size_t want = (n + rows_per_part - 1) / rows_per_part;
   if (want == 0) want = 1;
   if (want > (static_cast<size_t>(1) << 20)) want = static_cast<size_t>(1) << 20;  // 2^20 partitions at most
   unsigned lg = 0;
@@ -106,10 +115,18 @@ inline JlLayout jl_layout(size_t n) {
   if (want <= 1024) {  // one scatter level handles up to 1024 buckets
     L.log2_k2 = 0;
   } else {
-    L.log2_k2 = (lg + DBHIP_JL_K2_BIAS) / 2;  // split of the partition bits between the two scatter levels
+    // split of the partition bits between the two scatter levels, by floor(log2(parts)): between two powers of two
+    // level 0 takes the extra buckets (37504 partitions as 293 x 128: one side of 2^26 rows 615 us; as 147 x 256: 639)
+    const unsigned lgs = (static_cast<size_t>(1) << lg) != want ? lg - 1 : lg;
+    L.log2_k2 = (lgs + DBHIP_JL_K2_BIAS) / 2;
   }
   L.k2 = 1u << L.log2_k2;
   L.k1 = static_cast<unsigned>((want + L.k2 - 1) / L.k2);
+  while (L.k1 > 1024) {  // level 0 (one workgroup of 1024 threads owns the bucket offsets) takes at most 1024 buckets
+    ++L.log2_k2;
+    L.k2 <<= 1;
+    L.k1 = static_cast<unsigned>((want + L.k2 - 1) / L.k2);
+  }
   L.parts = L.k1 * L.k2;
   const size_t col = align_up((n ? n : 1) * sizeof(unsigned), kWsAlign);
   L.table_off = kWsHeader;

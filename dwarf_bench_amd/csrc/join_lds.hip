@@ -1650,7 +1650,7 @@ struct JrLayout {
   size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, giant_off, total;
 };
 JrLayout jr_layout(size_t n_build, size_t n_probe) {
-  const JlLayout G = jl_layout(n_build);
+  const JlLayout G = jl_layout(n_build, kJrRowsPerPart);
   JrLayout L;
   L.parts = G.parts; L.k1 = G.k1; L.k2 = G.k2; L.log2_k2 = G.log2_k2;
   L.meta_bytes = G.meta_bytes;

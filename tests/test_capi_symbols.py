@@ -54,3 +54,15 @@ def test_product_has_no_oracle_import():
     for py in (ROOT / "dwarf_bench_amd").rglob("*.py"):
         src = py.read_text()
         assert "pyoracle" not in src and "import oracle" not in src and "from oracle" not in src, py
+
+
+def test_join_partition_geometry_for_every_row_count(tmp_path):
+    """join_common.hpp jl_layout over row counts up to 2^31, for the build's and the radix join's rows per partition:
+    at most 1024 level-0 buckets, a power-of-two level-1 fan-out, partitions that hold their rows (tests/cpp/
+    join_layout_check.cpp; a geometry with 1171 level-0 buckets at 2^30 rows once made that join take a minute)"""
+    import subprocess
+    exe = tmp_path / "join_layout_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-w", "-I", str(ROOT / "dwarf_bench_amd" / "csrc"),
+                    str(ROOT / "tests" / "cpp" / "join_layout_check.cpp"), "-o", str(exe)], check=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "join layout ok" in r.stdout, r.stdout[-2000:]

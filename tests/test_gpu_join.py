@@ -139,7 +139,7 @@ def _keys_of_partition(n_build, partition, how_many):
     """distinct keys that the build of n_build rows puts into one partition (join_lds.hip jl_pid: the high bits of
     fmix32(key) * parts; parts as join_common.hpp jl_layout has them)"""
     want = min(max(1, -(-n_build // 2048)), 1 << 20)
-    lg = (want - 1).bit_length()
+    lg = want.bit_length() - 1  # floor(log2(want))
     k2 = 1 if want <= 1024 else 1 << (lg // 2)
     parts = -(-want // k2) * k2
     cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
