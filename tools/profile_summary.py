@@ -62,10 +62,10 @@ CONFIGS = {
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
     "groupby_2p26_2p16": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", r"gb_reduce\w*kernel"),
     # (the two launches for giant partitions close a build; they find none on the bench's uniform keys)
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_giant_ids_kernel"),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
     # the radix join: both sides through the partitioner, then the fused build + probe launch (+ two for giants)
-    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>|jl_giant_\w+_kernel", r"jl_hist0_kernel|jl_hist_fused_kernel", r"jl_giant_ids_kernel"),
+    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>|jl_giant_\w+_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
 }
 # a kernel of ANOTHER configuration that shares kernels with this one: a call that meets it is not this configuration's
 FOREIGN = {"join_build": r"jl_build_kernel<true>", "join_radix_2p26": r"jl_build_kernel<false>|jl_probe_kernel"}
