@@ -30,6 +30,12 @@ def _keys(rng, n, kind):
         return np.full(n, int(rng.integers(0, 2**32 - 1)), dtype=np.uint32)             # all equal
     if kind == 3:
         return rng.integers(0, 4, size=n, dtype=np.uint32) * np.uint32(0x01000000)      # only one byte varies
+    if kind == 5:                                                                       # 90 % one value, the rest anything
+        k = po.gen_uniform_u32(n, int(rng.integers(1, 1 << 30)), 0, 2**32 - 1)
+        k[rng.random(n) < 0.9] = np.uint32(rng.integers(0, 2**32 - 1))
+        return k
+    if kind == 6:                                                                       # two distinct values in every byte
+        return np.where(rng.integers(0, 2, size=n) == 1, np.uint32(0xFFFFFFFF), np.uint32(0))
     return np.sort(po.gen_uniform_u32(n, int(rng.integers(1, 1 << 30)), 0, max(n, 1)))  # sorted, many duplicates
 
 
@@ -51,7 +57,7 @@ def test_fuzz_sort():
     from dwarf_bench_amd import ops
     rng = np.random.default_rng(102)
     for n in _sizes(rng, 40, 21):
-        keys = _keys(rng, n, int(rng.integers(0, 5)))
+        keys = _keys(rng, n, int(rng.integers(0, 8)))
         bits = int(rng.choice([4, 8]))
         signed = bool(rng.integers(0, 2))
         t = _dev(keys)
@@ -92,6 +98,41 @@ def test_fuzz_join():
             for which in (0, -1):  # first and last id of every bucket carry the probe key
                 at = pos[hit] + (cnt[hit] - 1 if which else 0)
                 assert np.array_equal(build[ids[at]], probe[hit]), (nb, npr, hi)
+
+
+def test_fuzz_joins_with_hot_keys():
+    """both join paths on 2^18 .. 2^21 build rows with zero to three hot keys of 2 .. 60 % of a side, narrow and wide key
+    ranges (50 distinct keys: every partition that holds rows is a giant one): counts per probe row, ids a permutation in
+    which every key is one run, ranges that start and end in their key's run — against numpy"""
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(2026)
+    for _ in range(10):
+        nb = int(rng.integers(1 << 18, 1 << 21))
+        npr = int(rng.integers(1000, 1 << 20))
+        hi = int(rng.choice([nb, 10000, 2**32 - 2, 50]))
+        hb = rng.integers(0, hi, nb, dtype=np.uint64).astype(np.uint32)
+        hp = rng.integers(0, hi, npr, dtype=np.uint64).astype(np.uint32)
+        for _k in range(int(rng.integers(0, 4))):
+            key = np.uint32(rng.integers(0, hi))
+            frac = rng.choice([0.02, 0.1, 0.3, 0.6])
+            side = rng.integers(0, 3)
+            if side in (0, 2):
+                hb[rng.random(nb) < frac] = key
+            if side in (1, 2):
+                hp[rng.random(npr) < frac] = key
+        want = po.join_counts_fast(hb, hp).astype(np.uint32)
+        runs = np.unique(hb).size
+        pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.hash_join(_dev(hb), _dev(hp)))
+        assert np.array_equal(cnt, want) and np.array_equal(np.sort(ids), np.arange(nb, dtype=np.uint32))
+        in_order, hit = hb[ids], cnt > 0
+        assert np.count_nonzero(in_order[1:] != in_order[:-1]) + 1 == runs
+        assert np.array_equal(in_order[pos[hit]], hp[hit]) and np.array_equal(in_order[pos[hit] + cnt[hit] - 1], hp[hit])
+        rid, pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.radix_join(_dev(hb), _dev(hp)))
+        assert np.array_equal(np.sort(rid), np.arange(npr, dtype=np.uint32)) and np.array_equal(cnt, want[rid])
+        assert np.array_equal(np.sort(ids), np.arange(nb, dtype=np.uint32))
+        in_order, hit = hb[ids], cnt > 0
+        assert np.count_nonzero(in_order[1:] != in_order[:-1]) + 1 == runs
+        assert np.array_equal(in_order[pos[hit]], hp[rid[hit]]) and np.array_equal(in_order[pos[hit] + cnt[hit] - 1], hp[rid[hit]])
 
 
 def test_fuzz_ujoin():
