@@ -10,7 +10,10 @@ five 1 GiB copies in rotation).  The other single-GPU configurations of BASELINE
 rows / 2^16 groups, hash join 2^26 x 2^26 — row-ordered probe and radix join) and the 2^30 x 2^30 join on one GPU
 (`pjoin_p1`, the P = 1 point of the partitioned join) are measured in the same run with a few steps each and reported
 under "dwarfs" (they are not the headline value).
-N > 1 (launched by torch.distributed.run, one rank per GPU): the headline stays the same metric — scan does not
+N > 1, one rank per GPU — either under torch.distributed.run (RANK / WORLD_SIZE in the environment) or as plain
+`python bench.py --gpus N`, which then starts its own N rank processes before it imports torch or touches a GPU
+(self_launch; a WORLD_SIZE that differs from --gpus, or a rank without a GPU of its own, ends non-zero instead of
+printing a line with another n_gpus): the headline stays the same metric — scan does not
 shard ("replicas only"), so every rank runs the 2^28 scan on its own GPU and `value` is the aggregate (weak
 scaling) — and the one part of the path that does shard, the radix-partitioned hash join 2^30 x 2^30 with its
 RCCL all-to-all, is measured in the same run (strong scaling) and reported under "pjoin": on the C++ engine of the
@@ -673,6 +676,83 @@ def run_pjoin_children(args, rank):
     return {"error": f"the partitioned-join child of rank 0 ended with exit code {proc.returncode} and no result line"}
 
 
+def _free_port_pair():
+    """a port p with p and p + 1 both free on 127.0.0.1 (the partitioned-join children rendezvous one port up)"""
+    import socket
+    for _ in range(64):
+        with socket.socket() as a:
+            a.bind(("127.0.0.1", 0))
+            p = a.getsockname()[1]
+            if p >= 65535:
+                continue
+            with socket.socket() as b:
+                try:
+                    b.bind(("127.0.0.1", p + 1))
+                except OSError:
+                    continue
+        return p
+    raise SystemExit("bench.py: found no pair of free rendezvous ports on 127.0.0.1")
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): this process becomes
+    the launcher — it starts the N ranks as CHILD processes of itself (never an exec: nothing here has touched the GPU or
+    imported torch, and nothing will), one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the
+    way torch.distributed.run sets them, passes rank 0's stdout through (the ONE JSON line), and leaves with a non-zero
+    code if any rank did.  The reference's CLI starts everything it needs from one command too (main.cpp:13-96)."""
+    import signal
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or _free_port_pair())
+    me = os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "DBENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, me] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    print(f"[bench] --gpus {n} without a launcher: started ranks 0..{n - 1} as child processes "
+          f"(pids {[p.pid for p in procs]}, rendezvous 127.0.0.1:{port})", file=sys.stderr, flush=True)
+    # rank 0's stdout is passed through line by line on a thread, so a rank that dies early is noticed while rank 0
+    # still waits in a collective for it
+    import threading
+    relay = threading.Thread(target=lambda: [print(l, end="", flush=True) for l in procs[0].stdout], daemon=True)
+    relay.start()
+    failed = None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        # the others may sit in a collective that will never complete: give them a moment, then end exactly the
+        # processes started above
+        t_end = time.time() + 20
+        while time.time() < t_end and any(procs[r].poll() is None for r in alive):
+            time.sleep(0.2)
+        for r in alive:
+            if procs[r].poll() is None:
+                procs[r].send_signal(signal.SIGTERM)
+        for r in alive:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    relay.join(timeout=10)
+    if failed is not None:
+        print(f"[bench] rank {failed[0]} ended with exit code {failed[1]}: this run measured nothing valid", file=sys.stderr, flush=True)
+        return failed[1] if 0 < failed[1] < 256 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -686,7 +766,16 @@ def main():
     ap.add_argument("--pjoin-child", action="store_true", help=argparse.SUPPRESS)  # see run_pjoin_children
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not ("WORLD_SIZE" in os.environ and "RANK" in os.environ) and not args.pjoin_child:
+        # no launcher around this process: be the launcher (before torch is imported or the GPU touched)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank, world, local = _dist_env()
+    if world != args.gpus:
+        # a line that says n_gpus = WORLD_SIZE under a command that says --gpus N would be a silent wrong measurement
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` "
+                         f"(it starts its own ranks) or under torch.distributed.run with --nproc-per-node N")
     # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer sharing between the ranks
     # fails with hipIpcGetMemHandle: invalid argument (already exported on the boxes; kept for any other launcher)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -698,6 +787,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     if os.environ.get("DBENCH_BACKEND", "nccl") != "nccl":  # rehearsal: ranks may share a GPU
         local %= torch.cuda.device_count()
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible, --gpus "
+                         f"{args.gpus}): RCCL needs one device per rank (DBENCH_BACKEND=gloo rehearses with shared GPUs)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:

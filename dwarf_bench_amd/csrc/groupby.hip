@@ -379,9 +379,12 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_big_kernel(
   // 12-15 us of every call, 256 workgroups on the same lines).  Scratch: the carry counters' LDS words.
   unsigned *s_dec = s_table + kGbMaxLdsGroups;          // [0, 1024): multiplicities of the sampled keys by key % 1024
   unsigned &s_flag = s_table[kGbMaxLdsGroups + 1024];   // the decision, for the other waves
-  if (may_pack == 2) {  // DBHIP_GB_PACKED=force (tests: every packed path whatever the sample would say)
+  // may_pack == 0: the launch carries only the wide table's LDS (kGbMaxLdsGroups + 32 words) — s_dec and s_flag do not
+  // exist then and are not touched (the argument is uniform over the grid, so are the barriers below)
+  if (may_pack == 0) {
+  } else if (may_pack == 2) {  // DBHIP_GB_PACKED=force (tests: every packed path whatever the sample would say)
     if (tid == 0) s_flag = 1;
-  } else if (may_pack == 0 || n4 < 3) {
+  } else if (n4 < 3) {
     if (tid == 0) s_flag = 0;
   } else if (tid < kWave) {
     for (unsigned i = lane; i < 1024; i += kWave) s_dec[i] = 0;
@@ -434,9 +437,12 @@ __global__ __launch_bounds__(THREADS) void gb_aggregate_big_kernel(
     const bool ok = n >= (static_cast<size_t>(1) << 25) && vmax < 65536u && kmax < 8u && top < 65536.0f;
     if (lane == 0) s_flag = ok ? 1u : 0u;
   }
-  __syncthreads();
-  const bool packed = s_flag != 0;
-  __syncthreads();  // the flag is one of the words the aggregation clears next
+  bool packed = false;
+  if (may_pack != 0) {
+    __syncthreads();
+    packed = s_flag != 0;
+    __syncthreads();  // the flag is one of the words the aggregation clears next
+  }
   if (blockIdx.x == 0 && tid == 0) hdr->mode = packed ? kGbModePacked : kGbModeWide;
   // (measured: plain, L2-allocating loads win from 4 readers per row on, non-temporal ones below)
   if (packed) {

@@ -73,3 +73,28 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+def test_gpus_n_must_match_the_world_it_runs_in():
+    """`--gpus 4` inside a 2-rank job would print an n_gpus = 2 line under a command that says 4: refused, non-zero,
+    before torch is imported"""
+    import os
+    env = {**os.environ, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE = 2" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """no WORLD_SIZE around `bench.py --gpus 2`: the process starts two rank processes itself and leaves with THEIR
+    failure when they fail (here: no GPU) — never a one-GPU line with exit code 0"""
+    import os
+    import torch
+    if torch.cuda.is_available():
+        return  # the GPU suite runs the real thing (tests/test_gpu_bench_launcher.py)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "started ranks 0..1 as child processes" in r.stderr and r.stderr.count("needs a GPU") == 2
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

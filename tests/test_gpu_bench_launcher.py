@@ -52,3 +52,35 @@ def test_a_hung_leg_costs_an_error_entry_and_a_nonzero_child_exit():
     pj = d["pjoin"]
     assert "watchdog" in pj.get("error", "") and "never returns" in pj["error"] and pj.get("child_exit_code") == 3, pj
     assert pj["torch_distributed_host"]["ms_per_step"] > 0
+
+
+def test_gpus_2_without_any_launcher_starts_its_own_ranks():
+    """the driver's command form, `python bench.py --gpus N`, with nothing around it: bench.py starts its N ranks as
+    child processes itself (rehearsed with two ranks sharing this GPU over gloo) and rank 0's ONE line says n_gpus = 2
+    and carries the partitioned-join section; a world that does not match --gpus is refused"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update({"DBENCH_BACKEND": "gloo", "DBENCH_PJOIN_LOG2": "20", "DBENCH_PJOIN_DEADLINE_S": "60"})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    host = d["pjoin"]["torch_distributed_host"]
+    assert host["matches_equal_single_gpu"] and host["ms_per_step"] > 0 and "error" not in d["pjoin"], d["pjoin"]
+    assert "started ranks 0..1 as child processes" in r.stderr
+
+
+def test_gpus_2_on_one_gpu_with_rccl_fails_loudly():
+    """RCCL needs a device per rank: on this one-GPU box `--gpus 2` must end non-zero with no line at all (never an
+    n_gpus = 1 line under a --gpus 2 command)"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box can really run two RCCL ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DBENCH_BACKEND")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "has no GPU of its own" in r.stderr
