@@ -38,7 +38,6 @@ constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
 #define DBHIP_JL_THREADS 512
 #endif
 constexpr int kJlThreads = DBHIP_JL_THREADS;  // scatter / histogram / probe workgroups
-constexpr int kJlWaves = kJlThreads / kWave;
 #ifndef DBHIP_JL_KPT
 #define DBHIP_JL_KPT 8
 #endif
@@ -74,20 +73,21 @@ __device__ __forceinline__ unsigned jl_pid_sel(unsigned key, unsigned parts) {
 constexpr unsigned kJlGroups = 64;
 constexpr unsigned kJlHistWgPerGroup = 32;
 
-__device__ __forceinline__ size_t jl_tiles_per_group(size_t n) {
-  const size_t tiles = (n + kJlTile - 1) / kJlTile;
-  return (tiles + kJlGroups - 1) / kJlGroups;
+// rows of a tile group: a whole number of the level-0 scatter's tiles (`tile` rows each — the scatter comes in three
+// tile shapes, see JlShape), so histogram and scatter agree on which rows are group g's
+__host__ __device__ __forceinline__ size_t jl_group_rows(size_t n, unsigned tile) {
+  const size_t tiles = (n + tile - 1) / tile;
+  return (tiles + kJlGroups - 1) / kJlGroups * tile;
 }
 
 template <bool RANK>
-__global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__restrict__ keys, size_t n,
+__global__ __launch_bounds__(kJlThreads) void jl_hist0_kernel(const unsigned *__restrict__ keys, size_t n, size_t group_rows,
                                                               unsigned parts, unsigned k2_shift,
                                                               unsigned k1, unsigned long long *counts_g) {
   extern __shared__ unsigned s_hist[];
   const unsigned group = blockIdx.x / kJlHistWgPerGroup, w = blockIdx.x % kJlHistWgPerGroup;
-  const size_t tpg = jl_tiles_per_group(n);
-  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
-  size_t hi = lo + tpg * kJlTile;
+  const size_t lo = static_cast<size_t>(group) * group_rows;
+  size_t hi = lo + group_rows;
   hi = hi < n ? hi : n;
   if (lo >= hi) return;
   for (unsigned i = threadIdx.x; i < k1; i += kJlThreads) s_hist[i] = 0;
@@ -121,15 +121,14 @@ constexpr unsigned kJlFusedMaxParts = DBHIP_JL_FUSED_MAX_PARTS;  // 0 disables t
 // and a quarter more (a rank of the 8-GPU join receives 2^27 rows +- a few thousand: 65537+ partitions)
 constexpr unsigned kJlFused16MaxParts = 80 * 1024;
 
-__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const unsigned *__restrict__ keys, size_t n,
+__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const unsigned *__restrict__ keys, size_t n, size_t group_rows,
                                                                         unsigned parts, unsigned *__restrict__ wgcnt) {
   extern __shared__ unsigned s_hist[];
   const unsigned group = blockIdx.x / kJlFusedWgPerGroup, w = blockIdx.x % kJlFusedWgPerGroup;
   for (unsigned i = threadIdx.x; i < parts; i += kJlFusedThreads) s_hist[i] = 0;
   __syncthreads();
-  const size_t tpg = jl_tiles_per_group(n);
-  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
-  size_t hi = lo + tpg * kJlTile;
+  const size_t lo = static_cast<size_t>(group) * group_rows;
+  size_t hi = lo + group_rows;
   hi = hi < n ? hi : n;
   if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
     // 16-byte loads, four in flight per lane (4-byte loads kept 16 KiB per CU in flight: 79 us for 256 MiB of keys)
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const un
 // even partition's counter wrapped and the odd one's now holds one too many) or out of bit 31 (the odd one wrapped) and
 // settles that in the global accumulators the reduce kernel adds to — correct for any input, and free for every input
 // that is not pathological.  The workgroup's row of wgcnt is the LDS image: parts / 2 words.
-__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const unsigned *__restrict__ keys, size_t n,
+__global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const unsigned *__restrict__ keys, size_t n, size_t group_rows,
                                                                           unsigned parts, unsigned log2_k2, unsigned k1,
                                                                           unsigned *__restrict__ wgcnt,
                                                                           unsigned long long *counts0g,
@@ -203,9 +202,8 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const 
       }
     }
   };
-  const size_t tpg = jl_tiles_per_group(n);
-  const size_t lo = static_cast<size_t>(group) * tpg * kJlTile;
-  size_t hi = lo + tpg * kJlTile;
+  const size_t lo = static_cast<size_t>(group) * group_rows;
+  size_t hi = lo + group_rows;
   hi = hi < n ? hi : n;
   if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
     const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
@@ -310,7 +308,7 @@ __global__ __launch_bounds__(256) void jl_hist_reduce_kernel(const unsigned *__r
 // bucket starts, per-group cursors and the tile index of every bucket (for the 1-D grid of level 1).
 // One workgroup, thread b owns bucket b (k1 <= 1024).
 __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long long *__restrict__ counts_g,
-                                                           unsigned k1, unsigned long long *cursors_g,
+                                                           unsigned k1, unsigned tile1, unsigned long long *cursors_g,
                                                            unsigned long long *starts, unsigned long long *tile_starts,
                                                            unsigned long long *totals_out) {
   __shared__ unsigned long long s_tot[1024], s_start[1025], s_tstart[1025];
@@ -320,8 +318,8 @@ __global__ __launch_bounds__(1024) void jl_offsets0_kernel(const unsigned long l
   if (b < k1)
     for (unsigned g = 0; g < kJlGroups; ++g) tot += counts_g[static_cast<size_t>(g) * k1 + b];
   s_tot[b] = tot;
-  // exclusive prefix over the buckets of rows and of 4096-row tiles: wave scans + a 16-entry pass
-  const unsigned long long tl = b < k1 ? (tot + kJlTile - 1) / kJlTile : 0ull;
+  // exclusive prefix over the buckets of rows and of level-1 tiles: wave scans + a 16-entry pass
+  const unsigned long long tl = b < k1 ? (tot + tile1 - 1) / tile1 : 0ull;  // tiles of the level-1 scatter (tile1 rows each)
   unsigned long long ir = tot, it = tl;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
@@ -402,17 +400,17 @@ __global__ __launch_bounds__(kJlThreads) void jl_offsets1_kernel(const unsigned 
 // consecutive addresses of a run.  LEVEL selects how the bucket is recomputed from the key on the way
 // out (0: pid >> arg, 1: pid & arg).  dest[j] == nb marks an invalid (out-of-range) row.
 // LDS: cnt[nb] | excl[nb] | base[nb] (u64) | keys[4096] | rids[4096] | 4 wave sums.
-constexpr size_t jl_scatter_lds_bytes(unsigned nb) {
-  return static_cast<size_t>(nb) * 16 + 2 * kJlTile * sizeof(unsigned) + sizeof(unsigned) * kJlWaves;
+constexpr size_t jl_scatter_lds_bytes(unsigned nb, unsigned tile = kJlTile, unsigned threads = kJlThreads) {
+  return static_cast<size_t>(nb) * 16 + 2 * static_cast<size_t>(tile) * sizeof(unsigned) + sizeof(unsigned) * (threads / kWave);
 }
 struct JlNoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 // before_stores(): called once, right before the tile's global stores are issued (the level-0 kernel waits there for
 // the next tile's prefetched keys: see jl_scatter0_kernel)
-template <int LEVEL, bool RANK = false, class Hook = JlNoHook>
-__device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], const unsigned (&rid)[kJlKpt],
-                                                const unsigned (&dest)[kJlKpt], unsigned nb, unsigned parts,
+template <int LEVEL, int THREADS, int KPT, bool RANK = false, class Hook = JlNoHook>
+__device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], const unsigned (&rid)[KPT],
+                                                const unsigned (&dest)[KPT], unsigned nb, unsigned parts,
                                                 unsigned arg, unsigned long long *cursors,
                                                 unsigned *__restrict__ out_keys, unsigned *__restrict__ out_rids,
                                                 unsigned *s_mem, Hook before_stores = Hook()) {
@@ -420,18 +418,18 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   unsigned *s_cnt = s_mem + 2 * nb;
   unsigned *s_excl = s_cnt + nb;
   unsigned *s_keys = s_excl + nb;
-  unsigned *s_rids = s_keys + kJlTile;
-  unsigned *s_wsum = s_rids + kJlTile;
+  unsigned *s_rids = s_keys + (THREADS * KPT);
+  unsigned *s_wsum = s_rids + (THREADS * KPT);
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
 
-  for (unsigned i = tid; i < nb; i += kJlThreads) s_cnt[i] = 0;
+  for (unsigned i = tid; i < nb; i += THREADS) s_cnt[i] = 0;
   __syncthreads();
-  unsigned rank[kJlKpt];
+  unsigned rank[KPT];
 #pragma unroll
-  for (int j = 0; j < kJlKpt; ++j) rank[j] = dest[j] < nb ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
+  for (int j = 0; j < KPT; ++j) rank[j] = dest[j] < nb ? atomicAdd(&s_cnt[dest[j]], 1u) : 0u;
   __syncthreads();
   // exclusive scan of the bucket counts (nb <= 1024: up to 4 consecutive buckets per thread)
-  const unsigned per = (nb + kJlThreads - 1) / kJlThreads;
+  const unsigned per = (nb + THREADS - 1) / THREADS;
   unsigned c[4] = {0, 0, 0, 0}, mine = 0;
 #pragma unroll
   for (unsigned u = 0; u < 4; ++u) {
@@ -446,7 +444,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   for (unsigned w = 0; w < wave; ++w) run += s_wsum[w];
   unsigned total = 0;
 #pragma unroll
-  for (int w = 0; w < kJlWaves; ++w) total += s_wsum[w];
+  for (int w = 0; w < (THREADS / kWave); ++w) total += s_wsum[w];
 #pragma unroll
   for (unsigned u = 0; u < 4; ++u) {
     const unsigned b = tid * per + u;
@@ -460,7 +458,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < kJlKpt; ++j) {
+  for (int j = 0; j < KPT; ++j) {
     if (dest[j] < nb) {
       const unsigned p = s_excl[dest[j]] + rank[j];
       s_keys[p] = key[j];
@@ -469,7 +467,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
   }
   __syncthreads();
   before_stores();
-  for (unsigned p = tid; p < total; p += kJlThreads) {
+  for (unsigned p = tid; p < total; p += THREADS) {
     const unsigned k = s_keys[p];
     const unsigned pid = jl_pid_sel<RANK>(k, parts);
     const unsigned d = LEVEL == 0 ? pid >> arg : pid & arg;
@@ -487,8 +485,10 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[kJlKpt], c
 }
 
 // level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
-template <bool RANK>
-__global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
+// THREADS x KPT rows per tile (JlShape); RIDS: row ids come as a column (the received pairs of the multi-GPU join) —
+// a template parameter so that the other callers do not carry the prefetched row-id registers
+template <bool RANK, bool RIDS, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ row_ids,
                                                                  unsigned long long first_row, size_t n,
                                                                  unsigned parts, unsigned k2_shift, unsigned k1,
@@ -496,13 +496,13 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
                                                                  unsigned *__restrict__ out_keys,
                                                                  unsigned *__restrict__ out_rids) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
-  const size_t tiles = (n + kJlTile - 1) / kJlTile;
+  const size_t tiles = (n + (THREADS * KPT) - 1) / (THREADS * KPT);
   // XCD-aware tile order (speed only, any order is correct): workgroups are dealt to the 8 XCDs round-robin by
   // blockIdx, so XCD x = blockIdx % 8 takes the tile groups g with g % 8 == x.  A (group, bucket) write frontier is
   // then advanced by ONE XCD, whose L2 merges the partial lines of consecutive runs before they leave for memory
   // (WRITE_SIZE 770 MB for 537 MB stored when every XCD touched every frontier; 338 -> 310 us at 2^26 rows).
   // The same slicing of the level-1 scatter (buckets b % 8 == x per XCD, persistent grid) measured no faster.
-  const size_t tpg = jl_tiles_per_group(n);
+  const size_t tpg = jl_group_rows(n, THREADS * KPT) / (THREADS * KPT);
   const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u, per_xcd = gridDim.x / 8u;  // host: grid % 8 == 0
   const size_t locals = (kJlGroups / 8) * tpg;
   // tile of the workgroup's `local`-th step, or `tiles` when that step has none (the ragged end of the last group)
@@ -511,56 +511,57 @@ __global__ __launch_bounds__(kJlThreads) void jl_scatter0_kernel(const unsigned 
     const size_t tile = *group * tpg + local % tpg;
     return local < locals && tile < tiles ? tile : tiles;
   };
-  auto load_tile = [&](size_t tile, unsigned (&k)[kJlKpt], unsigned (&r)[kJlKpt]) {
+  auto load_tile = [&](size_t tile, unsigned (&k)[KPT], unsigned (&r)[KPT]) {
 #pragma unroll
-    for (int j = 0; j < kJlKpt; ++j) {
-      const size_t idx = tile * kJlTile + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+    for (int j = 0; j < KPT; ++j) {
+      const size_t idx = tile * (THREADS * KPT) + static_cast<size_t>(j) * THREADS + threadIdx.x;
       const bool valid = tile < tiles && idx < n;
       k[j] = valid ? keys[idx] : 0u;
-      r[j] = valid && row_ids ? row_ids[idx] : 0u;
+      r[j] = RIDS && valid ? row_ids[idx] : 0u;
     }
   };
   // The next tile's keys are requested before the current tile's LDS work and waited for right before the current
   // tile's stores go out (vmcnt counts a wave's loads and stores in issue order: waiting for loads at the top of the
   // next step would also wait for every store of this one).  They cross the loop in registers moved by a v_mov the
   // compiler cannot see through — a loop-carried register that a load defined is waited for with vmcnt(0) at first use.
-  unsigned ckey[kJlKpt], crid[kJlKpt];
+  unsigned ckey[KPT], crid[KPT];
   size_t group = 0, tile = tile_of(slot, &group);
   load_tile(tile, ckey, crid);
 #pragma unroll
-  for (int j = 0; j < kJlKpt; ++j) {
+  for (int j = 0; j < KPT; ++j) {
     asm volatile("v_mov_b32 %0, %0" : "+v"(ckey[j]));
-    asm volatile("v_mov_b32 %0, %0" : "+v"(crid[j]));
+    if (RIDS) asm volatile("v_mov_b32 %0, %0" : "+v"(crid[j]));
   }
   for (size_t local = slot; local < locals; local += per_xcd) {
     size_t ngroup = 0;
     const size_t ntile = tile_of(local + per_xcd, &ngroup);
-    unsigned nkey[kJlKpt], nrid[kJlKpt], mkey[kJlKpt], mrid[kJlKpt];
+    unsigned nkey[KPT], nrid[KPT], mkey[KPT], mrid[KPT];
     load_tile(ntile, nkey, nrid);
     auto wait_next = [&]() {
 #pragma unroll
-      for (int j = 0; j < kJlKpt; ++j) {
+      for (int j = 0; j < KPT; ++j) {
         asm volatile("v_mov_b32 %0, %1" : "=v"(mkey[j]) : "v"(nkey[j]));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(mrid[j]) : "v"(nrid[j]));
+        if (RIDS) asm volatile("v_mov_b32 %0, %1" : "=v"(mrid[j]) : "v"(nrid[j]));
+        else mrid[j] = 0u;
       }
     };
     if (tile < tiles) {  // uniform over the workgroup
-      const size_t base = tile * kJlTile;
-      unsigned rid[kJlKpt], dest[kJlKpt];
+      const size_t base = tile * (THREADS * KPT);
+      unsigned rid[KPT], dest[KPT];
 #pragma unroll
-      for (int j = 0; j < kJlKpt; ++j) {
-        const size_t idx = base + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
+      for (int j = 0; j < KPT; ++j) {
+        const size_t idx = base + static_cast<size_t>(j) * THREADS + threadIdx.x;
         const bool valid = idx < n;
-        rid[j] = valid ? (row_ids ? crid[j] : static_cast<unsigned>(first_row + idx)) : 0u;
+        rid[j] = valid ? (RIDS ? crid[j] : static_cast<unsigned>(first_row + idx)) : 0u;
         dest[j] = valid ? jl_pid_sel<RANK>(ckey[j], parts) >> k2_shift : k1;
       }
       // this tile bumps only its group's cursors
-      jl_scatter_tile<0, RANK>(ckey, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem, wait_next);
+      jl_scatter_tile<0, THREADS, KPT, RANK>(ckey, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem, wait_next);
     } else {
       wait_next();
     }
 #pragma unroll
-    for (int j = 0; j < kJlKpt; ++j) {
+    for (int j = 0; j < KPT; ++j) {
       ckey[j] = mkey[j];
       crid[j] = mrid[j];
     }
@@ -611,29 +612,35 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const u32x2 *__res
     if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
 }
 
-__global__ __launch_bounds__(kJlThreads) void jl_scatter1_kernel(const u32x2 *__restrict__ rows,
+template <int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void jl_scatter1_kernel(const u32x2 *__restrict__ rows,
                                                                  const unsigned long long *__restrict__ starts0,
                                                                  const unsigned long long *__restrict__ tile_starts,
                                                                  unsigned parts, unsigned k1, unsigned k2,
                                                                  unsigned long long *cursors1,
-                                                                 u32x2 *__restrict__ out_pairs) {
+                                                                 u32x2 *__restrict__ out_pairs, unsigned xcd_slices) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
   unsigned bucket;
   unsigned long long tile;
-  if (!jl_locate(tile_starts, k1, blockIdx.x, &bucket, &tile)) return;
-  const size_t lo = starts0[bucket] + tile * kJlTile;
+  // xcd_slices: workgroups are dealt to the 8 XCDs round-robin by blockIdx; XCD x then takes the x-th contiguous eighth of
+  // the virtual tiles, i.e. a level-0 bucket's tiles — which all append to the same k2 write frontiers — meet in ONE L2
+  // (host: gridDim.x % 8 == 0)
+  const unsigned long long vt = xcd_slices ? static_cast<unsigned long long>(blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u
+                                           : blockIdx.x;
+  if (!jl_locate(tile_starts, k1, vt, &bucket, &tile)) return;
+  const size_t lo = starts0[bucket] + tile * (THREADS * KPT);
   const size_t hi = starts0[bucket + 1];
-  unsigned key[kJlKpt], rid[kJlKpt], dest[kJlKpt];
+  unsigned key[KPT], rid[KPT], dest[KPT];
 #pragma unroll
-  for (int j = 0; j < kJlKpt; ++j) {
-    const size_t idx = lo + static_cast<size_t>(j) * kJlThreads + threadIdx.x;
-    const bool valid = idx < hi && idx < lo + kJlTile;
+  for (int j = 0; j < KPT; ++j) {
+    const size_t idx = lo + static_cast<size_t>(j) * THREADS + threadIdx.x;
+    const bool valid = idx < hi && idx < lo + (THREADS * KPT);
     const u32x2 row = valid ? rows[idx] : u32x2{0u, 0u};
     key[j] = row.x;
     rid[j] = row.y;
     dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
   }
-  jl_scatter_tile<1>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
+  jl_scatter_tile<1, THREADS, KPT>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
                      reinterpret_cast<unsigned *>(out_pairs), nullptr, s_mem);
 }
 
@@ -1466,6 +1473,8 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
 
 // grid of the level-0 scatter: a multiple of 8 (one slice of workgroups per XCD)
 inline unsigned jl_scatter0_grid(size_t tiles, size_t cap) {
+  static const int forced = [] { const char *e = getenv("DBHIP_JL_SC0_WGS"); return e ? atoi(e) : 0; }();  // experiment knob: workgroups per CU
+  if (forced >= 1 && forced <= 32) cap = cap / 8 * static_cast<size_t>(forced);
   size_t g = tiles < cap ? tiles : cap;
   g = (g + 7) / 8 * 8;
   return static_cast<unsigned>(g ? g : 8);
@@ -1475,6 +1484,107 @@ inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
   const size_t want = (items + kJlThreads - 1) / kJlThreads;
   const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
   return static_cast<unsigned>(want < cap ? (want ? want : 1) : cap);
+}
+
+
+// ---- tile shapes of the two scatter levels ---------------------------------------------------------------------------
+// 0: 512 threads x 8 rows = 4096-row tiles (36 KiB + 16 B per bucket of LDS: four workgroups per CU by LDS, two by their
+//    84 VGPRs) — the shape every size up to 2^27 rows was tuned on;
+// 1: 1024 x 8 = 8192 rows;  2: 1024 x 16 = 16384 rows (128 KiB of LDS: one workgroup per CU).
+// A tile of T rows into nb buckets writes runs of T / nb rows and takes one returning global atomic per bucket: with the
+// 586 x 1024 buckets of a 2^30-row side a 4096-row tile writes 56- and 32-byte runs and one atomic per 7 / 4 rows (level 0
+// at 2.8 TB/s, level 1 at 2.6, against 4.0 / 3.9 at 2^26 rows with 293 x 128 buckets).  DBHIP_JL_T0 / DBHIP_JL_T1 force a
+// shape (experiments).
+struct JlShape {
+  int t0, t1;
+};
+inline unsigned jl_shape_rows(int id) { return id == 0 ? 4096u : id == 1 ? 8192u : 16384u; }
+inline unsigned jl_shape_threads(int id) { return id == 0 ? 512u : 1024u; }
+inline int jl_env_shape(const char *name) {
+  const char *e = getenv(name);
+  return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : -1;
+}
+inline JlShape jl_shape_for(size_t n, unsigned k1, unsigned k2) {
+  static const int f0 = jl_env_shape("DBHIP_JL_T0"), f1 = jl_env_shape("DBHIP_JL_T1");
+  (void)n;
+  JlShape sh{0, 0};
+#ifndef DBHIP_JL_BIG_TILE_FROM
+#define DBHIP_JL_BIG_TILE_FROM 100000  // buckets of a level from which it takes the larger tiles (set by measurement below)
+#endif
+  if (k1 >= DBHIP_JL_BIG_TILE_FROM) sh.t0 = 2;
+  if (k2 >= DBHIP_JL_BIG_TILE_FROM) sh.t1 = 2;
+  if (f0 >= 0) sh.t0 = f0;
+  if (f1 >= 0) sh.t1 = f1;
+  return sh;
+}
+
+template <bool RANK, bool RIDS, int THREADS, int KPT>
+hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
+                                    unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
+                                    unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids) {
+  constexpr unsigned kTile = THREADS * KPT;
+  const size_t lds = jl_scatter_lds_bytes(k1, kTile, THREADS);
+  auto kernel = jl_scatter0_kernel<RANK, RIDS, THREADS, KPT>;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  const size_t tiles = (n + kTile - 1) / kTile;
+  // persistent grid: the shape of 4096-row tiles keeps its eight workgroups per CU (measured equal from two to eight), the
+  // larger ones as many as are resident
+  size_t per_cu = 8;
+  if (kTile > 4096) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
+      (void)hipGetLastError();
+      blocks = 1;
+    }
+    per_cu = static_cast<size_t>(blocks);
+  }
+  hipLaunchKernelGGL(kernel, dim3(jl_scatter0_grid(tiles, static_cast<size_t>(dev.cus) * per_cu)), dim3(THREADS), lds, s, keys,
+                     row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids);
+  return hipSuccess;
+}
+template <bool RANK>
+hipError_t jl_launch_scatter0(int shape, const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
+                              unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
+                              unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids) {
+#define JL_SC0(RIDS, T, K) \
+  jl_launch_scatter0_shape<RANK, RIDS, T, K>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids)
+  if (row_ids) {
+    if (RANK) return hipErrorInvalidValue;  // (the rank-level partition numbers its rows itself)
+    return shape == 0 ? JL_SC0(!RANK, 512, 8) : shape == 1 ? JL_SC0(!RANK, 1024, 8) : JL_SC0(!RANK, 1024, 16);
+  }
+  return shape == 0 ? JL_SC0(false, 512, 8) : shape == 1 ? JL_SC0(false, 1024, 8) : JL_SC0(false, 1024, 16);
+#undef JL_SC0
+}
+
+template <int THREADS, int KPT>
+hipError_t jl_launch_scatter1_shape(hipStream_t s, size_t n, const u32x2 *rows, const unsigned long long *starts0,
+                                    const unsigned long long *tstarts0, unsigned parts, unsigned k1, unsigned k2,
+                                    unsigned long long *cursors1, u32x2 *out) {
+  constexpr unsigned kTile = THREADS * KPT;
+  const size_t lds = jl_scatter_lds_bytes(k2, kTile, THREADS);
+  auto kernel = jl_scatter1_kernel<THREADS, KPT>;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  static const bool xcd = [] { const char *e = getenv("DBHIP_JL_SC1_XCD"); return !(e && e[0] == '0'); }();  // A/B knob
+  size_t vtiles = (n + kTile - 1) / kTile + k1;  // every bucket's last tile may be ragged
+  vtiles = (vtiles + 7) / 8 * 8;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(vtiles)), dim3(THREADS), lds, s, rows, starts0, tstarts0, parts, k1, k2,
+                     cursors1, out, xcd ? 1u : 0u);
+  return hipSuccess;
+}
+inline hipError_t jl_launch_scatter1(int shape, hipStream_t s, size_t n, const u32x2 *rows, const unsigned long long *starts0,
+                                     const unsigned long long *tstarts0, unsigned parts, unsigned k1, unsigned k2,
+                                     unsigned long long *cursors1, u32x2 *out) {
+  return shape == 0   ? jl_launch_scatter1_shape<512, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out)
+         : shape == 1 ? jl_launch_scatter1_shape<1024, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out)
+                      : jl_launch_scatter1_shape<1024, 16>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out);
 }
 
 }  // namespace
@@ -1514,7 +1624,8 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   // runs of 4r (the scatters are bound by partially written lines: level 1 went 330 -> 254 us at 2^26 rows when it
   // switched, level 0 followed once the level-1 histogram read pairs instead of a keys-only column)
   const unsigned k2_shift = log2_k2;
-  const size_t lds0 = jl_scatter_lds_bytes(k1);
+  const JlShape shape = jl_shape_for(n, k1, k2);
+  const size_t group_rows = jl_group_rows(n, jl_shape_rows(shape.t0));
   // two levels and at most 32768 partitions: both histograms from one read of the keys (wgcnt scratch: the level-1
   // output region, written only later by the level-1 scatter)
   // (8192..32768 partitions = 2^24..2^26 rows: level below it the two plain histograms are as fast, 2^22 rows: 77 vs 80 us)
@@ -1532,7 +1643,7 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (ea != hipSuccess) return static_cast<int>(ea);
     hipLaunchKernelGGL(jl_hist_fused16_kernel, dim3(kJlGroups * kJlFusedWgPerGroup), dim3(kJlFusedThreads), lds, s, keys, n,
-                       parts, log2_k2, k1, fused_scratch, counts0, counts1);
+                       group_rows, parts, log2_k2, k1, fused_scratch, counts0, counts1);
     const unsigned red_grid = (parts / 2 + 255) / 256 + (kJlGroups * kJlFusedWgPerGroup * k1 + 3) / 4;
     hipLaunchKernelGGL(jl_hist_reduce16_kernel, dim3(red_grid), dim3(256), 0, s, fused_scratch, parts, k1, k2, counts0, counts1);
   } else if (fused) {
@@ -1540,27 +1651,23 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(parts * sizeof(unsigned)));
     if (ea != hipSuccess) return static_cast<int>(ea);
     hipLaunchKernelGGL(jl_hist_fused_kernel, dim3(kJlGroups * kJlFusedWgPerGroup), dim3(kJlFusedThreads),
-                       parts * sizeof(unsigned), s, keys, n, parts, fused_scratch);
+                       parts * sizeof(unsigned), s, keys, n, group_rows, parts, fused_scratch);
     const unsigned red_grid = (parts + 255) / 256 + (kJlGroups * kJlFusedWgPerGroup * k1 + 3) / 4;
     hipLaunchKernelGGL(jl_hist_reduce_kernel, dim3(red_grid), dim3(256), 0, s, fused_scratch, parts, k1, k2, counts0, counts1);
   } else {
     hipLaunchKernelGGL(jl_hist0_kernel<false>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
-                       k1 * sizeof(unsigned), s, keys, n, parts, k2_shift, k1, counts0);
+                       k1 * sizeof(unsigned), s, keys, n, group_rows, parts, k2_shift, k1, counts0);
   }
-  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, cursors0, starts0, tstarts0,
-                     static_cast<unsigned long long *>(nullptr));
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, jl_shape_rows(shape.t1), cursors0, starts0,
+                     tstarts0, static_cast<unsigned long long *>(nullptr));
   {
-    const size_t tiles = (n + kJlTile - 1) / kJlTile;
-    const size_t cap = static_cast<size_t>(dev.cus) * 8;
-    hipLaunchKernelGGL(jl_scatter0_kernel<false>, dim3(jl_scatter0_grid(tiles, cap)), dim3(kJlThreads),
-                       lds0, s, keys, row_ids, 0ull, n, parts, k2_shift, k1, cursors0,
-                       reinterpret_cast<unsigned *>(rows_a), static_cast<unsigned *>(nullptr));
+    const hipError_t es = jl_launch_scatter0<false>(shape.t0, dev, s, keys, row_ids, 0ull, n, parts, k2_shift, k1, cursors0,
+                                                    reinterpret_cast<unsigned *>(rows_a), static_cast<unsigned *>(nullptr));
+    if (es != hipSuccess) return static_cast<int>(es);
   }
   *out_pairs = reinterpret_cast<const unsigned *>(rows_a);
   *out_starts = starts0;
   if (k2 > 1) {
-    const unsigned vtiles = static_cast<unsigned>((n + kJlTile - 1) / kJlTile + k1);
-    const size_t lds1 = jl_scatter_lds_bytes(k2);
     if (!fused && !fused16)
       hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
                          rows_a, starts0, parts, k2, counts1);
@@ -1571,8 +1678,8 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
     //  precomputed {bucket, tile} map in place of the workgroup's binary search over tile_starts — eight dependent
     //  loads in front of its row loads — measured the same as well (partition of 2^26 rows 610 vs 615 us), and so did
     //  the tile shapes 512x16 / 512x4 / 1024x4 once more (723 / 661 / 699 us against 610).)
-    hipLaunchKernelGGL(jl_scatter1_kernel, dim3(vtiles), dim3(kJlThreads), lds1, s, rows_a, starts0, tstarts0,
-                       parts, k1, k2, cursors1, rows_b);
+    const hipError_t e1 = jl_launch_scatter1(shape.t1, s, n, rows_a, starts0, tstarts0, parts, k1, k2, cursors1, rows_b);
+    if (e1 != hipSuccess) return static_cast<int>(e1);
     *out_pairs = reinterpret_cast<const unsigned *>(rows_b);
     *out_starts = starts1;
   }
@@ -1599,12 +1706,27 @@ bool jl_no_giants() {  // DBHIP_JL_NO_GIANTS=1: every partition through the per-
   static const bool off = [] { const char *v = getenv("DBHIP_JL_NO_GIANTS"); return v && v[0] == '1'; }();
   return off;
 }
+// Resident workgroups per CU of a persistent kernel, as the runtime computes it from the kernel's REGISTERS as well as
+// its LDS (round 4: the build kernels were launched with four 512-thread workgroups per CU — what their 24 KiB of LDS
+// allow — while their 73-79 VGPRs allow six waves per SIMD, i.e. three: a quarter of the statically dealt partitions
+// belonged to workgroups that only started when the first ones had finished).  `env`: experiment knob, workgroups per CU.
+template <class Kernel>
+unsigned jl_resident_per_cu(Kernel kernel, int threads, size_t lds, const char *env, unsigned fallback) {
+  const char *e = getenv(env);
+  const int forced = e ? atoi(e) : 0;
+  if (forced >= 1 && forced <= 32) return static_cast<unsigned>(forced);
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, lds) != hipSuccess || blocks < 1) {
+    (void)hipGetLastError();
+    return fallback;
+  }
+  return static_cast<unsigned>(blocks);
+}
+template <bool kMatch>
 unsigned jl_build_grid(unsigned parts, const DeviceInfo &dev) {
-  // as many 512-thread workgroups per CU as their LDS tables allow (24 KiB each at 3072 slots: four)
-  const size_t lds = jl_build_lds_bytes();
-  const size_t by_lds = (160 * 1024) / (lds + 1024), by_threads = 2048 / kJlBuildThreads;
-  const size_t per_cu = by_lds < by_threads ? by_lds : by_threads;
-  const size_t cap = static_cast<size_t>(dev.cus) * (per_cu ? per_cu : 1);
+  static const unsigned per_cu = jl_resident_per_cu(jl_build_kernel<kMatch>, kJlBuildThreads, jl_build_lds_bytes(),
+                                                    kMatch ? "DBHIP_JL_MATCH_WGS" : "DBHIP_JL_BUILD_WGS", 3u);
+  const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
   return static_cast<unsigned>(parts < cap ? parts : cap);
 }
 }  // namespace
@@ -1629,7 +1751,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
     const hipError_t eg = fill_async(giants.base, 0, jl_giant_header_bytes(L.max_giants), s);
     if (eg != hipSuccess) return static_cast<int>(eg);
   }
-  hipLaunchKernelGGL(jl_build_kernel<false>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, p.keys,
+  hipLaunchKernelGGL(jl_build_kernel<false>, dim3(jl_build_grid<false>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, p.keys,
                      p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
                      JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, giants);
   if (giants.max) {
@@ -1723,7 +1845,7 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
   }
   const JlMatchArgs match{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt};
   unsigned *status = reinterpret_cast<unsigned *>(base);
-  hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
+  hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid<true>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
                      static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
                      static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, status, match, giants);
   if (giants.max) {
@@ -1819,15 +1941,13 @@ int jl_partition(const unsigned *keys, size_t n, unsigned long long first_row, u
   hipError_t e = fill_async(base, 0, jl_partition_workspace_bytes(parts), s);
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL(jl_hist0_kernel<true>, dim3(kJlGroups * kJlHistWgPerGroup), dim3(kJlThreads),
-                     parts * sizeof(unsigned), s, keys, n, parts, 0u, parts, counts0);
-  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, parts, cursors0, starts0, tstarts0,
-                     out_counts);
+                     parts * sizeof(unsigned), s, keys, n, jl_group_rows(n, kJlTile), parts, 0u, parts, counts0);
+  hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, parts, static_cast<unsigned>(kJlTile), cursors0,
+                     starts0, tstarts0, out_counts);
   if (n) {
-    const size_t tiles = (n + kJlTile - 1) / kJlTile;
-    const size_t cap = static_cast<size_t>(dev.cus) * 8;
-    hipLaunchKernelGGL(jl_scatter0_kernel<true>, dim3(jl_scatter0_grid(tiles, cap)), dim3(kJlThreads),
-                       jl_scatter_lds_bytes(parts), s, keys, static_cast<const unsigned *>(nullptr), first_row, n, parts,
-                       0u, parts, cursors0, out_keys, out_rids);
+    e = jl_launch_scatter0<true>(0, dev, s, keys, static_cast<const unsigned *>(nullptr), first_row, n, parts, 0u, parts,
+                                 cursors0, out_keys, out_rids);
+    if (e != hipSuccess) return static_cast<int>(e);
   }
   return launch_status();
 }

@@ -14,6 +14,7 @@ the contract numbers come from bench.py.
   groupby-skew    2^26 rows whose keys crowd into one or a few groups, at 64 .. 2^16 groups (median of 5)
   sort-shapes [lg] 2^lg keys of eight distributions (few distinct values, sorted, reversed, skewed ...; median of 5)
   join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
+  radix [lg]      the radix join alone at 2^lg x 2^lg (default 30: the P = 1 point of the partitioned join)
   join-skew [lg]  the same over key shapes (hot keys, strided keys, sorted, few distinct keys; median of 3)
   size-sweep      every dwarf at sizes next to and between powers of two, 2^13 .. 2^26 (geometry cliffs)
   partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
@@ -243,6 +244,31 @@ def join(lg):
           f"(partition one side {pb:7.1f}, match {m:7.1f}) matches {'equal' if ok else 'DIFFER'}", flush=True)
 
 
+def radix(lg):
+    """the radix join alone (no table in HBM): sizes up to 2^30 x 2^30 fit; the match count is printed so that variants
+    can be compared with each other (at 2^26 it is checked against torch by `join`)"""
+    lg = lg or 30
+    n = 1 << lg
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    rj = ops.RadixJoin(n, n)
+
+    def run():
+        rj.partition_build(build)
+        rj.partition_probe(probe)
+        rj.match()
+
+    k = 5 if lg >= 29 else 7
+    r = dropmax(times(run, k, warm=1))
+    pb = dropmax(times(lambda: rj.partition_build(build), k, warm=0))
+    m = dropmax(times(rj.match, k, warm=0))
+    rj.result()
+    total = int(rj.cnt.to(torch.int64).sum())
+    ids_ok = int(rj.ids.to(torch.int64).sum()) == n * (n - 1) // 2  # the id buffer is a permutation of the build rows
+    print(f"{TAG:20s} 2^{lg}: radix join {r:9.1f} us (partition one side {pb:8.1f}, match {m:8.1f}) matches {total} "
+          f"ids {'a permutation sum' if ids_ok else 'WRONG'}", flush=True)
+
+
 def _matches(build, probe):
     """number of (build row, probe row) pairs with equal keys, by torch"""
     bk, bc = torch.unique(u64(build), return_counts=True)
@@ -463,7 +489,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
+MODES = {"radix": radix, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
