@@ -753,7 +753,16 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   // (two arrays instead of three: 48 KiB per workgroup at 6144 slots, three workgroups per CU)
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
   __shared__ unsigned s_end;  // where the last slot's id range ends = first position behind the partition's counted rows
+  __shared__ unsigned s_ticket;  // the ticket thread 0 took for the partition after the next one
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  // Partitions by ticket (round 4).  A static deal (partition p, p + grid, ...) ends when the SLOWEST workgroup has walked
+  // its share, and workgroups are not equally fast (CUs share L2 slices and memory channels unevenly): the fused kernel
+  // took 669 us for the 37504 partitions of 2^26 rows, 49 per workgroup, and 8903 us / 16 = 556 us per 2^26 rows at 2^30,
+  // 781 per workgroup, where the differences average out.  The first partition is blockIdx, every further one comes from
+  // a counter in the workspace header (status[32]; status[33] counts the workgroups that have left: the last one zeroes
+  // both for the next launch).  The ticket is taken one step ahead of the prefetch, by thread 0, and handed over
+  // through LDS where the prefetched rows are waited for — a returning atomic counts in vmcnt like a load.
+  unsigned *const ticket_word = status + 32, *const left_word = status + 33;
   // a partition holds ~kJlRowsPerPart rows (+ 6 sigma of a Poisson count): rows per thread whose slot and row id
   // stay in registers between steps 1 and 3, and rows per thread loaded one partition ahead
   constexpr int kJlCached = static_cast<int>((kJlRowsPerPart + kJlRowsPerPart / 8 + kJlBuildThreads - 1) / kJlBuildThreads);
@@ -767,6 +776,13 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   size_t part = blockIdx.x;
   if (part >= parts) return;
   size_t lo = starts[part], hi = starts[part + 1];
+  size_t npart = parts;  // the partition after this one
+  {
+    if (tid == 0) s_ticket = atomicAdd(ticket_word, 1u);
+    __syncthreads();
+    npart = static_cast<size_t>(gridDim.x) + s_ticket;
+    __syncthreads();
+  }
   u32x2 carry[kJlPre];  // the current partition's rows, in registers that no load is pending on
 #pragma unroll
   for (int r = 0; r < kJlPre; ++r) {
@@ -780,11 +796,12 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   }
   while (true) {
     // the offsets this step needs, requested together: the next partition's rows and (radix join) this partition's probe rows
-    const size_t npart = part + gridDim.x;
     size_t nlo = 0, nhi = 0, slo = 0, shi = 0;
+    unsigned tk = 0;
     if (npart < parts) {
       nlo = starts[npart];
       nhi = starts[npart + 1];
+      if (tid == 0) tk = atomicAdd(ticket_word, 1u);  // for the step after the next (consumed below, with the prefetch)
     }
     if (kMatch) {
       slo = match.sstarts[part];
@@ -919,6 +936,11 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       asm volatile("v_mov_b32 %0, %1" : "=v"(nxt[r].x) : "v"(pre[r].x));
       asm volatile("v_mov_b32 %0, %1" : "=v"(nxt[r].y) : "v"(pre[r].y));
     }
+    if (tid == 0 && npart < parts) {  // (read by everyone behind the barrier that closes this step)
+      unsigned got;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(got) : "v"(tk));
+      s_ticket = got;
+    }
     if (!kMatch) {
     // 3. publish the sub-table: {key, first position | count field} for every slot.  Positions are an exclusive scan
     //    in slot order, so slot i ends where slot i+1 starts (the last one at s_end).  Output stores are what this
@@ -1043,10 +1065,17 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     if (npart >= parts) break;
     JL_BUILD_BARRIER();  // the LDS arrays and s_wsum are reused by the next partition
     part = npart;
+    npart = static_cast<size_t>(gridDim.x) + s_ticket;
     lo = nlo;
     hi = nhi;
 #pragma unroll
     for (int r = 0; r < kJlPre; ++r) carry[r] = nxt[r];
+  }
+  // every ticket this workgroup asked for has been answered (each was consumed above): the last workgroup to leave
+  // resets the two words, so a launch finds them zero without a fill in front of it
+  if (tid == 0 && atomicAdd(left_word, 1u) + 1u == gridDim.x) {
+    __hip_atomic_store(ticket_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(left_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1507,12 +1536,13 @@ inline int jl_env_shape(const char *name) {
 inline JlShape jl_shape_for(size_t n, unsigned k1, unsigned k2) {
   static const int f0 = jl_env_shape("DBHIP_JL_T0"), f1 = jl_env_shape("DBHIP_JL_T1");
   (void)n;
+  // Measured (radix join, us, t0/t1; same box): 2^26 rows (293 x 128 buckets) 0/0 1838, 1/1 1862, 2/2 2039; 2^27 (293 x 256)
+  // 0/0 3406, 1/1 3502, 2/2 3805; 2^28 (586 x 256) 0/0 7776, 1/0 7521, 2/0 7261, 2/1 7425, 2/2 8089; 2^29 (586 x 512) 0/0
+  // 16214, 2/0 15225, 1/1 15196, 2/1 14567, 2/2 15836; 2^30 (586 x 1024) 0/0 35256, 2/0 33994, 0/2 33265, 1/2 32852, 2/2 32558.
   JlShape sh{0, 0};
-#ifndef DBHIP_JL_BIG_TILE_FROM
-#define DBHIP_JL_BIG_TILE_FROM 100000  // buckets of a level from which it takes the larger tiles (set by measurement below)
-#endif
-  if (k1 >= DBHIP_JL_BIG_TILE_FROM) sh.t0 = 2;
-  if (k2 >= DBHIP_JL_BIG_TILE_FROM) sh.t1 = 2;
+  if (k1 >= 512) sh.t0 = 2;
+  if (k2 >= 1024) sh.t1 = 2;
+  else if (k2 >= 512) sh.t1 = 1;
   if (f0 >= 0) sh.t0 = f0;
   if (f1 >= 0) sh.t1 = f1;
   return sh;
