@@ -87,9 +87,27 @@ inline unsigned jr_max_giants(size_t n_build, size_t n_probe) {
 }
 constexpr unsigned kJlMaxGiantList = 2052;  // >= 2 * (1024 + 1) + 1: the giant kernels' LDS list
 
+// SPILLED partitions (round 4): a partition with more DISTINCT keys than its sub-table has slots.  The mixing hash puts
+// 2048 +- 45 keys into a partition, so only keys constructed against the hash get there — but the reference's table takes
+// any input (ht_size = 2 * distinct, join/join_omnisci.cpp:69-70; omnisci_hashtable.hpp:80-108 probes until it finds a
+// slot), so this library does too: such a partition is published as an empty sub-table, listed, and built by ONE workgroup
+// into an open-addressing table of its own in HBM (memory-side atomics: slow, correct for any input; jl_spill_partition
+// in join_lds.hip), and probes of its keys go there through a per-partition directory.  Scratch, behind the giants':
+//   dir[parts] {first slot + 1 | 0, slots}  |  list[max]  |  keys[pool] | pos[pool] | cnt[pool]
+// A spilled partition of R rows takes R + R/2 + 64 slots of the pool; there are fewer than n / kJlSubSlots + 2 of them.
+// Header words of the workspace: [34] listed partitions, [35] pool slots taken.
+constexpr unsigned kJlHdrTicket = 32, kJlHdrLeft = 33, kJlHdrSpilled = 34, kJlHdrSpillPool = 35;
+__host__ __device__ __forceinline__ unsigned jl_max_spill(size_t n) { return static_cast<unsigned>(n / kJlSubSlots + 2); }
+__host__ __device__ __forceinline__ size_t jl_spill_cap(size_t rows) { return rows + rows / 2 + 64; }
+__host__ __device__ __forceinline__ size_t jl_spill_pool_slots(size_t n) { return n + n / 2 + 64 * static_cast<size_t>(jl_max_spill(n)); }
+__host__ __device__ __forceinline__ size_t jl_spill_list_words(size_t n) { return (static_cast<size_t>(jl_max_spill(n)) + 3) & ~static_cast<size_t>(3); }
+inline size_t jl_spill_bytes(unsigned parts, size_t n) {
+  return align_up(8 * static_cast<size_t>(parts) + 4 * jl_spill_list_words(n) + 12 * jl_spill_pool_slots(n), kWsAlign);
+}
+
 struct JlLayout {
   unsigned parts, k1, k2, log2_k2, max_giants;
-  size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, giant_off, total;
+  size_t table_off, keys_a_off, rids_a_off, keys_b_off, rids_b_off, meta_off, meta_bytes, giant_off, spill_off, total;
 };
 
 // The radix join's fused build + probe kernel likes its partitions emptier than the build kernel does (2^26 x 2^26, rows
@@ -139,7 +157,8 @@ inline JlLayout jl_layout(size_t n, size_t rows_per_part = kJlRowsPerPart) {
   L.meta_bytes = sizeof(unsigned long long) * ((2 * 64 + 2) * static_cast<size_t>(L.k1) + 2 + 3 * static_cast<size_t>(L.parts) + 1);  // 64 = kJlGroups
   L.max_giants = jl_max_giants(n);
   L.giant_off = align_up(L.meta_off + L.meta_bytes, kWsAlign);
-  L.total = align_up(L.giant_off + jl_giant_bytes(L.max_giants), kWsAlign);
+  L.spill_off = align_up(L.giant_off + jl_giant_bytes(L.max_giants), kWsAlign);
+  L.total = L.spill_off + jl_spill_bytes(L.parts, n);
   return L;
 }
 

@@ -655,8 +655,9 @@ __device__ __forceinline__ u32x2 jl_row(const unsigned *__restrict__ pkeys, cons
 
 // Slot of `key` in the LDS key array `lk`: a plain read first — a key that is already there (a duplicate row) and
 // every step of a collision chain need no atomic — ds_cmpst only on a slot read as empty.  Returns kJlSubSlots for
-// the sentinel key (flagged) and for a full table (flagged).
-__device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigned *status) {
+// the sentinel key (flagged in the status word) and for a full sub-table — more distinct keys than slots: *full (an LDS
+// word of the caller) is set, the caller hands the partition to the spill path.
+__device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigned *status, unsigned *full) {
   if (key == kEmptyKey) {  // the sentinel is not a key (join/join_omnisci.cpp:52): flag it, drop the row
     atomicOr(status, DBHIP_DEV_KEY_RANGE);
     return kJlSubSlots;
@@ -668,7 +669,7 @@ __device__ __forceinline__ unsigned jl_claim(unsigned *lk, unsigned key, unsigne
     if (k == kEmptyKey || k == key) return s;
     s = jl_next_slot(s);
   }
-  atomicOr(status, DBHIP_DEV_TABLE_FULL);
+  *full = 1u;
   return kJlSubSlots;
 }
 
@@ -738,14 +739,160 @@ struct JlGiants {
   }
   __host__ __device__ unsigned *cursors(unsigned g) const { return counts(max) + static_cast<size_t>(g) * kJlSubSlots; }
 };
-template <bool kMatch>
+// The spilled partitions' scratch (join_common.hpp).
+struct JlSpill {
+  unsigned *area;  // dir[parts] {first slot + 1 | 0, slots} | list[max_list] | keys[pool] | pos[pool] | cnt[pool]
+  unsigned parts, max_list, list_words;
+  unsigned long long pool;
+  __host__ __device__ u32x2 *dir() const { return reinterpret_cast<u32x2 *>(area); }
+  __host__ __device__ unsigned *list() const { return area + 2 * static_cast<size_t>(parts); }
+  __host__ __device__ unsigned *keys() const { return list() + list_words; }
+  __host__ __device__ unsigned *pos() const { return keys() + pool; }
+  __host__ __device__ unsigned *cnt() const { return pos() + pool; }
+};
+// (a pure function of the build's partition and row counts: the build kernels take only the area's address — their scalar
+//  registers are all in use — and derive the rest where the rare path needs it)
+__host__ __device__ __forceinline__ JlSpill jl_spill_of(void *area, unsigned parts, size_t n) {
+  return JlSpill{static_cast<unsigned *>(area), parts, jl_max_spill(n), static_cast<unsigned>(jl_spill_list_words(n)),
+                 static_cast<unsigned long long>(jl_spill_pool_slots(n))};
+}
+__device__ __forceinline__ unsigned jl_spill_home(unsigned key, unsigned cap) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key * 0x9E3779B1u ^ 0x7F4A7C15u)) * cap) >> 32);
+}
+__device__ __forceinline__ unsigned jl_ld(const unsigned *p) {  // a read that no stale line of this CU's L1 can answer
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// {first id position, count} of `key` in the spilled partition's table [base, base + cap), {0, 0} if it is not there
+__device__ __forceinline__ void jl_spill_lookup(const JlSpill &sp, unsigned base, unsigned cap, unsigned key, unsigned *pos_out,
+                                                unsigned *cnt_out) {
+  *pos_out = *cnt_out = 0;
+  if (key == kEmptyKey) return;
+  const unsigned *keys = sp.keys() + base;
+  unsigned s = jl_spill_home(key, cap);
+  for (unsigned tries = 0; tries < cap; ++tries) {
+    const unsigned k = jl_ld(&keys[s]);
+    if (k == key) {
+      *pos_out = jl_ld(&sp.pos()[base + s]);
+      *cnt_out = jl_ld(&sp.cnt()[base + s]);
+      return;
+    }
+    if (k == kEmptyKey) return;
+    s = s + 1 == cap ? 0u : s + 1;
+  }
+}
+// One workgroup (kJlGiantThreads = kJlBuildThreads threads, all of them call this together) builds the table of partition
+// `part` — rows [lo, hi) of the partition-major pairs — in the pool and writes the partition's ids[lo, hi); radix join
+// (match.spairs != nullptr): it then answers the partition's probe rows.  Correct for any rows; not written to be fast:
+// every step is a memory-side atomic (a hot key of such a partition is served at one atomic per ~11 ns).
+// `sub` (one-to-many build, a giant that spilled): the partition's sub-table of the published table, which jl_giant_count
+// left half-claimed — it is rewritten as an empty, MARKED one (jl_probe_sub; the build kernel publishes a spilled
+// partition of its own that way itself).
+__device__ __noinline__ void jl_spill_partition(const JlSpill sp, const u32x2 *__restrict__ rows, size_t lo, size_t hi, unsigned part,
+                                                unsigned *__restrict__ ids, unsigned *status, const JlMatchArgs match, size_t slo,
+                                                size_t shi, u32x2 *sub, unsigned pos_bits) {
+  constexpr unsigned kT = kJlBuildThreads;
+  __shared__ unsigned s_base, s_w[kT / kWave];
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned cap = static_cast<unsigned>(jl_spill_cap(hi - lo));
+  __syncthreads();
+  if (tid == 0) s_base = atomicAdd(status + kJlHdrSpillPool, cap);
+  __syncthreads();
+  const unsigned base = s_base;
+  if (static_cast<unsigned long long>(base) + cap > sp.pool) {  // (cannot happen: the pool holds every partition that can spill)
+    if (tid == 0) atomicOr(status, DBHIP_DEV_TABLE_FULL);
+    return;
+  }
+  unsigned *keys = sp.keys() + base, *pos = sp.pos() + base, *cnt = sp.cnt() + base;
+  for (unsigned i = tid; i < cap; i += kT) {
+    keys[i] = kEmptyKey;
+    cnt[i] = 0;
+  }
+  __threadfence();
+  __syncthreads();
+  // 1. distinct keys and their row counts
+  for (size_t i = lo + tid; i < hi; i += kT) {
+    const unsigned key = rows[i].x;
+    if (key == kEmptyKey) {  // the sentinel is not a key (join/join_omnisci.cpp:52): flagged, the row is dropped
+      atomicOr(status, DBHIP_DEV_KEY_RANGE);
+      continue;
+    }
+    unsigned s = jl_spill_home(key, cap);
+    while (true) {  // (cap > rows >= distinct keys: an empty slot exists)
+      const unsigned k = atomicCAS(&keys[s], kEmptyKey, key);
+      if (k == kEmptyKey || k == key) break;
+      s = s + 1 == cap ? 0u : s + 1;
+    }
+    atomicAdd(&cnt[s], 1u);
+  }
+  __threadfence();
+  __syncthreads();
+  // 2. first id position of every key: exclusive scan of the counts in slot order, from the partition's first position
+  unsigned run = static_cast<unsigned>(lo);
+  for (unsigned c0 = 0; c0 < cap; c0 += kT) {  // (uniform)
+    const unsigned i = c0 + tid;
+    const unsigned c = i < cap && jl_ld(&keys[i]) != kEmptyKey ? jl_ld(&cnt[i]) : 0u;
+    const unsigned incl = wave_inclusive_scan(c);
+    if (lane == kWave - 1) s_w[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+    for (unsigned w = 0; w < kT / kWave; ++w) {
+      before += w < wave ? s_w[w] : 0u;
+      total += s_w[w];
+    }
+    if (i < cap) pos[i] = run + before + incl - c;
+    run += total;
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  // 3. ids: every row takes the next place of its key's range (the position word is the cursor; step 4 puts it back)
+  for (size_t i = lo + tid; i < hi; i += kT) {
+    const u32x2 row = rows[i];
+    if (row.x == kEmptyKey) continue;
+    unsigned s = jl_spill_home(row.x, cap);
+    while (jl_ld(&keys[s]) != row.x) s = s + 1 == cap ? 0u : s + 1;
+    ids[atomicAdd(&pos[s], 1u)] = row.y;
+  }
+  __threadfence();
+  __syncthreads();
+  for (unsigned i = tid; i < cap; i += kT)
+    if (jl_ld(&keys[i]) != kEmptyKey) pos[i] = jl_ld(&pos[i]) - jl_ld(&cnt[i]);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) sp.dir()[part] = u32x2{base + 1u, cap};
+  if (sub != nullptr) {
+    const unsigned word = static_cast<unsigned>(lo) | (pos_bits < 32 ? 1u << pos_bits : 0u);
+    for (unsigned i = tid; i < kJlSubSlots; i += kT) sub[i] = u32x2{kEmptyKey, word};
+  }
+  // 4. radix join: the partition's probe rows
+  if (match.spairs != nullptr)
+    for (size_t j = slo + tid; j < shi; j += kT) {
+      const u32x2 row = match.spairs[j];
+      unsigned p, c;
+      jl_spill_lookup(sp, base, cap, row.x, &p, &c);
+      match.out_rid[j] = row.y;
+      match.out_pos[j] = p;
+      match.out_cnt[j] = c;
+    }
+  __syncthreads();
+}
+// a workgroup whose partition does not fit its sub-table lists it for the spill path (thread 0)
+__device__ __forceinline__ void jl_spill_list(const JlSpill &sp, unsigned part, unsigned *status) {
+  const unsigned g = atomicAdd(status + kJlHdrSpilled, 1u);
+  if (g < sp.max_list) sp.list()[g] = part;
+  else atomicOr(status, DBHIP_DEV_TABLE_FULL);  // (cannot happen: fewer partitions can spill than the list holds)
+}
+
+// kInline: the workgroup that finds its partition overfull builds the spill table itself, at once (small inputs: no
+// launch behind this one looks at the list); otherwise it lists the partition for the tail of jl_giant_ids_kernel.
+template <bool kMatch, bool kInline>
 __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu(6))) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
                                                                    u32x2 *__restrict__ table, unsigned parts,
                                                                    unsigned n_rows, unsigned pos_bits,
                                                                    unsigned *__restrict__ ids, unsigned *status,
-                                                                   JlMatchArgs match, JlGiants giants) {
+                                                                   JlMatchArgs match, JlGiants giants, unsigned *spill_area) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_lds[];
   unsigned *lk = s_lds;                // keys
   unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
@@ -754,6 +901,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
   __shared__ unsigned s_end;  // where the last slot's id range ends = first position behind the partition's counted rows
   __shared__ unsigned s_ticket;  // the ticket thread 0 took for the partition after the next one
+  __shared__ unsigned s_full;    // a row of this partition found the sub-table full of other keys
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   // Partitions by ticket (round 4).  A static deal (partition p, p + grid, ...) ends when the SLOWEST workgroup has walked
   // its share, and workgroups are not equally fast (CUs share L2 slices and memory channels unevenly): the fused kernel
@@ -762,10 +910,11 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   // a counter in the workspace header (status[32]; status[33] counts the workgroups that have left: the last one zeroes
   // both for the next launch).  The ticket is taken one step ahead of the prefetch, by thread 0, and handed over
   // through LDS where the prefetched rows are waited for — a returning atomic counts in vmcnt like a load.
-  unsigned *const ticket_word = status + 32, *const left_word = status + 33;
+  unsigned *const ticket_word = status + kJlHdrTicket, *const left_word = status + kJlHdrLeft;
   // a partition holds ~kJlRowsPerPart rows (+ 6 sigma of a Poisson count): rows per thread whose slot and row id
   // stay in registers between steps 1 and 3, and rows per thread loaded one partition ahead
-  constexpr int kJlCached = static_cast<int>((kJlRowsPerPart + kJlRowsPerPart / 8 + kJlBuildThreads - 1) / kJlBuildThreads);
+  constexpr unsigned kRowsPerPart = kMatch ? kJrRowsPerPart : kJlRowsPerPart;  // (the radix join partitions for fewer rows)
+  constexpr int kJlCached = static_cast<int>((kRowsPerPart + kRowsPerPart / 8 + kJlBuildThreads - 1) / kJlBuildThreads);
   constexpr int kJlPre = kJlCached;  // every cached row comes from the prefetch: a row loaded inside the claim phase made
                                      // the compiler wait (s_waitcnt vmcnt(0)) for the prefetch issued just before it too
   static_assert(static_cast<unsigned>(kJlCached) * kJlBuildThreads <= kJlSubSlots, "a partition without overflow rows fits the id staging area");
@@ -773,20 +922,20 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   // Persistent workgroups walk the partitions with a stride of the grid; a workgroup is a chain of dependent
   // phases (load, claim, scan, fill, publish), so the NEXT partition's rows are requested before the current
   // partition's LDS work starts and arrive while it runs.
-  size_t part = blockIdx.x;
+  unsigned part = blockIdx.x;
   if (part >= parts) return;
-  size_t lo = starts[part], hi = starts[part + 1];
-  size_t npart = parts;  // the partition after this one
+  unsigned lo = static_cast<unsigned>(starts[part]), hi = static_cast<unsigned>(starts[part + 1]);  // (32-bit: n <= 2^31 rows; the kernel is short of scalar registers)
+  unsigned npart = parts;  // the partition after this one
   {
     if (tid == 0) s_ticket = atomicAdd(ticket_word, 1u);
     __syncthreads();
-    npart = static_cast<size_t>(gridDim.x) + s_ticket;
+    npart = static_cast<unsigned>(gridDim.x) + s_ticket;
     __syncthreads();
   }
   u32x2 carry[kJlPre];  // the current partition's rows, in registers that no load is pending on
 #pragma unroll
   for (int r = 0; r < kJlPre; ++r) {
-    const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+    const unsigned i = lo + tid + static_cast<unsigned>(r) * kJlBuildThreads;
     carry[r] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
   }
 #pragma unroll
@@ -796,16 +945,16 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   }
   while (true) {
     // the offsets this step needs, requested together: the next partition's rows and (radix join) this partition's probe rows
-    size_t nlo = 0, nhi = 0, slo = 0, shi = 0;
+    unsigned nlo = 0, nhi = 0, slo = 0, shi = 0;
     unsigned tk = 0;
     if (npart < parts) {
-      nlo = starts[npart];
-      nhi = starts[npart + 1];
+      nlo = static_cast<unsigned>(starts[npart]);
+      nhi = static_cast<unsigned>(starts[npart + 1]);
       if (tid == 0) tk = atomicAdd(ticket_word, 1u);  // for the step after the next (consumed below, with the prefetch)
     }
     if (kMatch) {
-      slo = match.sstarts[part];
-      shi = match.sstarts[part + 1];
+      slo = static_cast<unsigned>(match.sstarts[part]);
+      shi = static_cast<unsigned>(match.sstarts[part + 1]);
     }
     if (giants.max != 0 && (hi - lo > giants.rows || (kMatch && shi - slo > giants.probe_rows))) {  // (uniform)
       // a giant partition (join_common.hpp): listed for the jl_giant_* kernels, which all workgroups share.  Build: it is
@@ -831,6 +980,10 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       lk[i] = kEmptyKey;
       lc[i] = 0;
     }
+    if (tid == 0) {
+      s_full = 0;
+      reinterpret_cast<u32x2 *>(spill_area)[part] = u32x2{0u, 0u};  // "not spilled" (every partition passes here exactly once per build)
+    }
     u32x2 cur[kJlPre];
 #pragma unroll
     for (int r = 0; r < kJlPre; ++r) cur[r] = carry[r];
@@ -840,7 +993,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     if (npart < parts) {
 #pragma unroll
       for (int r = 0; r < kJlPre; ++r) {
-        const size_t i = nlo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+        const unsigned i = nlo + tid + static_cast<unsigned>(r) * kJlBuildThreads;
         if (i < nhi) pre[r] = jl_row(pkeys, prids, i);
       }
     }
@@ -848,7 +1001,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     // while the sub-table is built
     u32x2 srow[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
     if (kMatch) {
-      const size_t j0 = slo + 4 * static_cast<size_t>(tid);
+      const unsigned j0 = slo + 4 * static_cast<unsigned>(tid);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (j0 + q < shi) srow[q] = match.spairs[j0 + q];
@@ -867,14 +1020,14 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     unsigned c_slot[kJlCached], c_rid[kJlCached], c_rank[kJlCached];
 #pragma unroll
     for (int r = 0; r < kJlCached; ++r) {
-      const size_t i = lo + tid + static_cast<size_t>(r) * kJlBuildThreads;
+      const unsigned i = lo + tid + static_cast<unsigned>(r) * kJlBuildThreads;
       c_slot[r] = kJlSubSlots;  // "no row"
       c_rid[r] = 0;
       c_rank[r] = 0;
       if (i < hi) {
         const u32x2 row = r < kJlPre ? cur[r < kJlPre ? r : 0] : jl_row(pkeys, prids, i);
         c_rid[r] = row.y;
-        const unsigned s = jl_claim(lk, row.x, status);
+        const unsigned s = jl_claim(lk, row.x, status, &s_full);
         if (s < kJlSubSlots) {
           c_slot[r] = s;
           c_rank[r] = atomicAdd(&lc[s], 1u);
@@ -883,27 +1036,48 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     }
     // a partition far above its expected size: the rows beyond the cached ones are counted AFTER every cached row has
     // its rank (so the cached rows of a key hold the ranks 0 .. k-1 and these rows own the ranks behind them)
-    const bool overflow = hi - lo > static_cast<size_t>(kJlCached) * kJlBuildThreads;  // uniform over the workgroup
+    const bool overflow = hi - lo > static_cast<unsigned>(kJlCached) * kJlBuildThreads;  // uniform over the workgroup
     if (overflow) {
       // (four rows per lane in flight and crowds of one key added by one lane, round 3: a partition of 2^16 rows of one
       //  key took a workgroup 2.6 ns per row with one load in flight and every lane's atomic on the same word)
       JL_BUILD_BARRIER();
-      for (size_t i0 = lo + static_cast<size_t>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+      for (unsigned i0 = lo + static_cast<unsigned>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<unsigned>(kJlBuildThreads)) {
         u32x2 row[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const size_t i = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid;
+          const unsigned i = i0 + static_cast<unsigned>(q) * kJlBuildThreads + tid;
           row[q] = i < hi ? jl_row(pkeys, prids, i) : u32x2{0u, 0u};
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const bool have = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid < hi;
-          const unsigned s = have ? jl_claim(lk, row[q].x, status) : kJlSubSlots;
+          const bool have = i0 + static_cast<unsigned>(q) * kJlBuildThreads + tid < hi;
+          const unsigned s = have ? jl_claim(lk, row[q].x, status, &s_full) : kJlSubSlots;
           (void)jl_take<true>(&lc[s < kJlSubSlots ? s : 0u], s, s < kJlSubSlots);
         }
       }
     }
     JL_BUILD_BARRIER();
+    const bool spilled = s_full != 0u;
+    if (spilled) {  // (uniform) more distinct keys than slots: the spill path builds this partition; here it becomes an
+                    // empty one — cleared counters scan to "every position = lo", which is what gets published; the rows'
+                    // stale slot / rank registers reach nothing (no counted rows are written out; guards below)
+      const JlSpill spill = jl_spill_of(spill_area, parts, n_rows);
+      if (kInline) {
+        jl_spill_partition(spill, reinterpret_cast<const u32x2 *>(pkeys), lo, hi, static_cast<unsigned>(part), ids, status, match,
+                           slo, shi, nullptr, pos_bits);
+        if (tid == 0) atomicAdd(status + kJlHdrSpilled, 1u);
+      } else if (tid == 0) {
+        jl_spill_list(spill, static_cast<unsigned>(part), status);
+      }
+      // (a build of exactly 2^31 rows has no count field to mark a spilled sub-table with: that one size still fails loudly)
+      if (!kMatch && pos_bits >= 32 && tid == 0) atomicOr(status, DBHIP_DEV_TABLE_FULL);
+      JL_BUILD_BARRIER();
+      for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
+        lk[i] = kEmptyKey;
+        lc[i] = 0;
+      }
+      JL_BUILD_BARRIER();
+    }
     // 2. exclusive scan of the counts -> first id position of every slot
     constexpr unsigned kPer = kJlSubSlots / kJlBuildThreads;
     unsigned c[kPer], mine = 0;
@@ -947,7 +1121,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     //    kernel waits for (per-instruction issue cost: with the stores compiled out it ran 150 us shorter at 2^26
     //    rows), so every store instruction carries 16 bytes per lane: two slots here, four ids below.  Written once,
     //    read by another launch: non-temporal.
-    u32x4 *dst = reinterpret_cast<u32x4 *>(table + part * kJlSubSlots);  // 16-byte aligned: kJlSubSlots is even
+    u32x4 *dst = reinterpret_cast<u32x4 *>(table + static_cast<size_t>(part) * kJlSubSlots);  // 16-byte aligned: kJlSubSlots is even
     const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
     for (unsigned i = tid; i < kJlSubSlots / 2; i += kJlBuildThreads) {
       const unsigned p0 = lp[2 * i], p1 = lp[2 * i + 1], p2 = 2 * i + 2 < kJlSubSlots ? lp[2 * i + 2] : s_end;
@@ -955,6 +1129,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       unsigned f0 = c0 ? c0 - 1 : 0u, f1 = c1 ? c1 - 1 : 0u;
       f0 = f0 < cnt_esc ? f0 : cnt_esc;
       f1 = f1 < cnt_esc ? f1 : cnt_esc;
+      if (spilled) f0 = f1 = 1u;  // (uniform) the mark on a spilled partition's empty slots: see jl_probe_sub
       const unsigned w0 = pos_bits < 32 ? (p0 | (f0 << pos_bits)) : p0, w1 = pos_bits < 32 ? (p1 | (f1 << pos_bits)) : p1;
       __builtin_nontemporal_store(u32x4{lk[2 * i], w0, lk[2 * i + 1], w1}, dst + i);
     }
@@ -965,8 +1140,9 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       //     FOUR consecutive rows per lane: one 16-byte store per output column and lane (4-byte stores made this
       //     kernel store-issue-bound: 914 us at 2^26 x 2^26 rows)
       typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-      const size_t jfirst = slo + 4 * static_cast<size_t>(tid);
-      for (size_t j0 = jfirst; j0 < shi; j0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+      const unsigned jfirst = slo + 4 * static_cast<unsigned>(tid);
+      if (!spilled)  // (a spilled partition's probe rows are answered by jl_spill_partition)
+      for (unsigned j0 = jfirst; j0 < shi; j0 += 4 * static_cast<unsigned>(kJlBuildThreads)) {
         unsigned rid[4], pos[4], cnt[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1031,7 +1207,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       }
       const unsigned tail0 = head + 4 * body;
       if (tid < 4 && tail0 + tid < rows) out[tail0 + tid] = stage[tail0 + tid];
-    } else {
+    } else if (!spilled) {
 #pragma unroll
       for (int r = 0; r < kJlCached; ++r)
         if (c_pos[r] != 0xFFFFFFFFu) ids[c_pos[r]] = c_rid[r];
@@ -1039,11 +1215,11 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
       // range downwards, decrementing a cursor that starts at the next slot's first position (for the last slot:
       // s_end) — after a barrier: the publish and the cached rows above still needed those words intact
       JL_BUILD_BARRIER();
-      for (size_t i0 = lo + static_cast<size_t>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<size_t>(kJlBuildThreads)) {
+      for (unsigned i0 = lo + static_cast<unsigned>(kJlCached) * kJlBuildThreads; i0 < hi; i0 += 4 * static_cast<unsigned>(kJlBuildThreads)) {
         u32x2 row[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const size_t i = i0 + static_cast<size_t>(q) * kJlBuildThreads + tid;
+          const unsigned i = i0 + static_cast<unsigned>(q) * kJlBuildThreads + tid;
           row[q] = i < hi ? jl_row(pkeys, prids, i) : u32x2{kEmptyKey, 0u};
         }
 #pragma unroll
@@ -1065,7 +1241,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
     if (npart >= parts) break;
     JL_BUILD_BARRIER();  // the LDS arrays and s_wsum are reused by the next partition
     part = npart;
-    npart = static_cast<size_t>(gridDim.x) + s_ticket;
+    npart = static_cast<unsigned>(gridDim.x) + s_ticket;
     lo = nlo;
     hi = nhi;
 #pragma unroll
@@ -1137,7 +1313,7 @@ __device__ __forceinline__ unsigned jl_giant_of(const unsigned *s_first, unsigne
 }
 // count the rows [a, b) per key in the LDS sub-table lk / lc (cleared here)
 __device__ __forceinline__ void jl_slice_count(const u32x2 *__restrict__ rows, size_t a, size_t b, unsigned *lk, unsigned *lc,
-                                               unsigned *status) {
+                                               unsigned *status, unsigned *full) {
   const unsigned tid = threadIdx.x;
   for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
     lk[i] = kEmptyKey;
@@ -1154,15 +1330,16 @@ __device__ __forceinline__ void jl_slice_count(const u32x2 *__restrict__ rows, s
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool have = i0 + static_cast<size_t>(q) * kJlGiantThreads + tid < b;
-      const unsigned sl = have ? jl_claim(lk, r[q].x, status) : kJlSubSlots;
+      const unsigned sl = have ? jl_claim(lk, r[q].x, status, full) : kJlSubSlots;
       (void)jl_take<true>(&lc[sl < kJlSubSlots ? sl : 0u], sl, sl < kJlSubSlots);
     }
   }
   __syncthreads();
 }
 // slot of `key` in the giant's sub-table in HBM; claim = true: take the first empty slot of its chain if it is not there
-// yet.  kJlSubSlots: the sub-table is full of other keys (flagged) / the key is not there.
-__device__ __forceinline__ unsigned jl_giant_slot(u32x2 *sub, unsigned key, bool claim, unsigned *status) {
+// yet.  kJlSubSlots: the sub-table is full of other keys (*full is set: the giant goes to the spill path) / the key is
+// not there.
+__device__ __forceinline__ unsigned jl_giant_slot(u32x2 *sub, unsigned key, bool claim, unsigned *full) {
   unsigned s = jl_home_slot(fmix32(key));
   for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
     unsigned *kw = reinterpret_cast<unsigned *>(sub + s);
@@ -1175,16 +1352,16 @@ __device__ __forceinline__ unsigned jl_giant_slot(u32x2 *sub, unsigned key, bool
     if (k == key) return s;
     s = jl_next_slot(s);
   }
-  if (claim) atomicOr(status, DBHIP_DEV_TABLE_FULL);
+  if (claim) *full = 1u;
   return kJlSubSlots;
 }
 
 __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u32x2 *__restrict__ rows,
                                                                          const unsigned long long *__restrict__ starts,
                                                                          u32x2 *table, unsigned pos_bits, JlGiants giants,
-                                                                         unsigned *status) {
+                                                                         unsigned *status, JlSpill spill) {
   __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
-  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave], s_last;
+  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave], s_last, s_full;
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   unsigned ng;
   const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
@@ -1194,13 +1371,14 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
     const size_t lo = starts[part], hi = starts[part + 1];
     const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
     const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
-    jl_slice_count(rows, a, b, lk, lc, status);
+    if (tid == 0) s_full = 0;
+    jl_slice_count(rows, a, b, lk, lc, status, &s_full);
     u32x2 *sub = giants.sub_table(table, g, part);
     unsigned *gcount = giants.counts(g);
-    for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
+    for (unsigned i = tid; i < kJlSubSlots && !s_full; i += kJlGiantThreads) {
       const unsigned c = lc[i];
       if (c) {
-        const unsigned gs = jl_giant_slot(sub, lk[i], true, status);
+        const unsigned gs = jl_giant_slot(sub, lk[i], true, &s_full);
         if (gs < kJlSubSlots) {
           const unsigned before = atomicAdd(&gcount[gs], c);
           asm volatile("" ::"v"(before));  // the lane waits for the atomic's answer: the add has been performed
@@ -1212,6 +1390,9 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
     // no fence.  (With __threadfence() on either side of the tick — a write-back and an invalidation of the XCD's whole
     // L2 each — this kernel took 2.1 ms for 500 giants of 2^16 rows: 9 slices each, every one stalling its XCD twice.)
     __syncthreads();
+    // more distinct keys than a sub-table has slots (in this slice, or in the giant as a whole): the giant goes to the spill
+    // path, listed once — the directory word doubles as the guard; what the other slices still count is never read
+    if (tid == 0 && s_full && atomicCAS(spill.area + 2 * static_cast<size_t>(part), 0u, 0xFFFFFFFFu) == 0u) jl_spill_list(spill, part, status);
     if (tid == 0) s_last = atomicAdd(&giants.done()[g], 1u) + 1u == s_first[g + 1] - s_first[g] ? 1u : 0u;
     __syncthreads();
     if (s_last) {  // (uniform)
@@ -1245,7 +1426,8 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
 }
 
 __device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
-                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out);
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out,
+                                             unsigned *marked);
 // (radix join, match.spairs != nullptr: the same launch then runs the listed partitions' PROBE rows against their scratch
 //  sub-tables, in slices of kJlSlice rows over all workgroups — they need the tables' position words, which
 //  jl_giant_count finished, not the ids; one 8-byte gather per row, a hot key's slot one cache line for everybody;
@@ -1254,9 +1436,9 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
                                                                         const unsigned long long *__restrict__ starts,
                                                                         u32x2 *table, JlGiants giants,
                                                                         unsigned *__restrict__ ids, unsigned *status,
-                                                                        JlMatchArgs match, unsigned pos_bits) {
+                                                                        JlMatchArgs match, unsigned pos_bits, JlSpill spill) {
   __shared__ unsigned lk[kJlSubSlots], lc[kJlSubSlots];
-  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave];
+  __shared__ unsigned s_first[kJlMaxGiantList], s_wsum[kJlGiantThreads / kWave], s_full;
   const unsigned tid = threadIdx.x;
   unsigned ng;
   const unsigned items = jl_giant_slices(giants, starts, s_first, s_wsum, &ng);
@@ -1266,14 +1448,15 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
     const size_t lo = starts[part], hi = starts[part + 1];
     const size_t a = lo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
     const size_t b = a + kJlSlice < hi ? a + kJlSlice : hi;
-    jl_slice_count(rows, a, b, lk, lc, status);
+    if (spill.dir()[part].x != 0u) continue;  // (uniform) a giant that went to the spill path: built at the end of this kernel
+    jl_slice_count(rows, a, b, lk, lc, status, &s_full);
     u32x2 *sub = giants.sub_table(table, g, part);
     unsigned *cursor = giants.cursors(g);
     // the slice's share of every key's id range: lc[i] becomes the first position of the share
     for (unsigned i = tid; i < kJlSubSlots; i += kJlGiantThreads) {
       const unsigned c = lc[i];
       if (c) {
-        const unsigned gs = jl_giant_slot(sub, lk[i], false, status);
+        const unsigned gs = jl_giant_slot(sub, lk[i], false, &s_full);
         lc[i] = gs < kJlSubSlots ? atomicAdd(&cursor[gs], c) : 0xFFFFFFFFu;  // (not there: only behind a full table, flagged)
       }
     }
@@ -1308,6 +1491,17 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
     }
     __syncthreads();  // lk / lc are reused by the next slice
   }
+  // the spilled partitions (listed by jl_build_kernel and jl_giant_count_kernel): one workgroup each
+  {
+    unsigned nsp = status[kJlHdrSpilled];
+    nsp = nsp < spill.max_list ? nsp : spill.max_list;
+    for (unsigned g = blockIdx.x; g < nsp; g += gridDim.x) {  // (uniform)
+      const unsigned part = spill.list()[g];
+      const size_t slo = match.spairs ? match.sstarts[part] : 0, shi = match.spairs ? match.sstarts[part + 1] : 0;
+      jl_spill_partition(spill, rows, starts[part], starts[part + 1], part, ids, status, match, slo, shi,
+                         table != nullptr ? table + static_cast<size_t>(part) * kJlSubSlots : nullptr, pos_bits);
+    }
+  }
   if (match.spairs == nullptr) return;
   __syncthreads();
   const unsigned pitems = jl_giant_slices(giants, match.sstarts, s_first, s_wsum, &ng);
@@ -1319,11 +1513,13 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
     const size_t slo = match.sstarts[part], shi = match.sstarts[part + 1];
     const size_t a = slo + static_cast<size_t>(item - s_first[g]) * kJlSlice;
     const size_t b = a + kJlSlice < shi ? a + kJlSlice : shi;
+    if (spill.dir()[part].x != 0u) continue;  // (uniform) spilled: its probe rows were answered by jl_spill_partition
     const u32x2 *sub = giants.scratch_table(g);
     for (size_t j = a + tid; j < b; j += kJlGiantThreads) {
       const u32x2 row = match.spairs[j];
       unsigned pos, cnt;
-      jl_probe_sub(row.x, fmix32(row.x), sub, pos_bits, pos_mask, cnt_esc, &pos, &cnt);
+      unsigned marked = 0;
+      jl_probe_sub(row.x, fmix32(row.x), sub, pos_bits, pos_mask, cnt_esc, &pos, &cnt, &marked);
       match.out_rid[j] = row.y;
       match.out_pos[j] = pos;
       match.out_cnt[j] = cnt;
@@ -1331,18 +1527,25 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_ids_kernel(const u32
   }
 }
 
-// one probe row: slot {key, first position | count field} by linear probing inside the key's sub-table
+// one probe row: slot {key, first position | count field} by linear probing inside the key's sub-table.
+// *marked |= the count field of the EMPTY slot a miss ended on: zero in every sub-table the build kernels publish
+// normally, non-zero in the sub-table of a partition whose keys live in the spill pool (jl_spill_partition) — the probe
+// learns that from the slot it reads anyway (a flag word in the workspace header, read once per wave, made the same
+// loop 7-11 % slower: 1557 -> 1670-1730 us at 2^26 rows on the same box, the branch never taken).
 __device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
-                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out);
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out,
+                                             unsigned *marked);
 __device__ __forceinline__ void jl_probe_row(unsigned key, const u32x2 *__restrict__ table, unsigned parts, unsigned pos_bits,
-                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out) {
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out,
+                                             unsigned *marked) {
   const unsigned h = fmix32(key);
   jl_probe_sub(key, h, table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots, pos_bits,
-               pos_mask, cnt_esc, pos_out, cnt_out);
+               pos_mask, cnt_esc, pos_out, cnt_out, marked);
 }
 // the same inside a given sub-table (h = fmix32(key))
 __device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32x2 *__restrict__ sub, unsigned pos_bits,
-                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out) {
+                                             unsigned pos_mask, unsigned cnt_esc, unsigned *pos_out, unsigned *cnt_out,
+                                             unsigned *marked) {
   unsigned s = jl_home_slot(h), pos = 0, cnt = 0;
   for (unsigned tries = 0; tries < kJlSubSlots && key != kEmptyKey; ++tries) {  // the sentinel never matches
     const u32x2 e = sub[s];
@@ -1353,75 +1556,44 @@ __device__ __forceinline__ void jl_probe_sub(unsigned key, unsigned h, const u32
       cnt = field < cnt_esc ? field + 1u : (sub[s + 1].y & pos_mask) - pos;
       break;
     }
-    if (e.x == kEmptyKey) break;
+    if (e.x == kEmptyKey) {
+      *marked |= pos_bits < 32 ? e.y >> pos_bits : 0u;
+      break;
+    }
     s = jl_next_slot(s);
   }
   *pos_out = pos;
   *cnt_out = cnt;
 }
 
-#ifndef DBHIP_JL_PROBE_ROWS
-#define DBHIP_JL_PROBE_ROWS 1  // 4 consecutive rows per lane (16-byte key loads / result stores, four gathers in flight per
-#endif                         // lane) measured SLOWER: 1852 vs 1434 us at 2^26 — the random-access path saturates sooner
 __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__restrict__ probe, size_t n,
                                                               const u32x2 *__restrict__ table, unsigned parts,
                                                               unsigned pos_bits, unsigned *__restrict__ out_pos,
-                                                              unsigned *__restrict__ out_cnt) {
+                                                              unsigned *__restrict__ out_cnt, JlSpill spill) {
   // The probe is pure memory latency: one random 8-byte gather per row = the slot {key, first position | count
   // field}; the right-hand neighbour is read only when the field holds the escape value.  (The first layout read
   // slot and neighbour with one 16-byte load at 8-byte alignment: every eighth row crossed a 64-byte line, i.e. one
-  // more memory request.)  A lane takes kRows CONSECUTIVE rows per step: one 16-byte key load, kRows gathers in
-  // flight, one 16-byte store per output column — with one row per step every gather was preceded by a key load and
-  // followed by a drain of the two 4-byte stores (vmcnt counts loads and stores together, in issue order).
-  constexpr int kRows = DBHIP_JL_PROBE_ROWS;
-  typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  // more memory request.  A variant with FOUR consecutive rows per lane — one 16-byte key load, four gathers in flight,
+  // one 16-byte store per output column — measured SLOWER, 1852 vs 1434 us at 2^26 rows: the random-access path
+  // saturates sooner; removed in round 4.)
   const unsigned pos_mask = pos_bits < 32 ? (1u << pos_bits) - 1u : 0xFFFFFFFFu;
   const unsigned cnt_esc = pos_bits < 32 ? (1u << (32 - pos_bits)) - 1u : 0u;
   const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
-  if (kRows == 4) {
-    const size_t quads = n / 4;
-    for (size_t q = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; q < quads; q += stride) {
-      const u32x4 k = *reinterpret_cast<const u32x4_a4 *>(probe + 4 * q);
-      const unsigned key[4] = {k.x, k.y, k.z, k.w};
-      // the four first-step gathers go out together; rows whose first slot is neither their key nor empty continue
-      // on their own below
-      const u32x2 *sub[4];
-      unsigned s0[4];
-      u32x2 e[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned h = fmix32(key[r]);
-        sub[r] = table + static_cast<size_t>((static_cast<unsigned long long>(h) * parts) >> 32) * kJlSubSlots;
-        s0[r] = jl_home_slot(h);
-        e[r] = sub[r][s0[r]];
-      }
-      unsigned pos[4], cnt[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pos[r] = cnt[r] = 0;
-        if (key[r] == kEmptyKey) continue;
-        unsigned s = s0[r];
-        u32x2 cur = e[r];
-        for (unsigned tries = 0; tries < kJlSubSlots; ++tries) {
-          if (cur.x == key[r]) {
-            pos[r] = cur.y & pos_mask;
-            const unsigned field = pos_bits < 32 ? cur.y >> pos_bits : 0u;
-            cnt[r] = field < cnt_esc ? field + 1u : (sub[r][s + 1].y & pos_mask) - pos[r];
-            break;
-          }
-          if (cur.x == kEmptyKey) break;
-          s = jl_next_slot(s);
-          cur = sub[r][s];
-        }
-      }
-      *reinterpret_cast<u32x4_a4 *>(out_pos + 4 * q) = u32x4{pos[0], pos[1], pos[2], pos[3]};
-      *reinterpret_cast<u32x4_a4 *>(out_cnt + 4 * q) = u32x4{cnt[0], cnt[1], cnt[2], cnt[3]};
-    }
-    const size_t i = quads * 4 + static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x;  // the n % 4 last rows
-    if (i < n) jl_probe_row(probe[i], table, parts, pos_bits, pos_mask, cnt_esc, out_pos + i, out_cnt + i);
-  } else {
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
-      jl_probe_row(probe[i], table, parts, pos_bits, pos_mask, cnt_esc, out_pos + i, out_cnt + i);
+  unsigned marked = 0;  // some row of this thread ended on an empty slot of a spilled partition's sub-table
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride)
+    jl_probe_row(probe[i], table, parts, pos_bits, pos_mask, cnt_esc, out_pos + i, out_cnt + i, &marked);
+  // Spilled partitions (never on hashed keys): a sub-table whose EMPTY slots carry a non-zero count field belongs to a
+  // partition whose keys are in the spill pool; a thread that met one goes over ITS rows again and answers those of
+  // spilled partitions from the pool (a hit cannot happen in such a sub-table: it holds no keys)
+  if (marked == 0u) return;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned key = probe[i];
+    const u32x2 d = spill.dir()[jl_pid(key, parts)];
+    if (d.x == 0u) continue;
+    unsigned p, c;
+    jl_spill_lookup(spill, d.x - 1u, d.y, key, &p, &c);
+    out_pos[i] = p;
+    out_cnt[i] = c;
   }
 }
 
@@ -1754,7 +1926,7 @@ unsigned jl_resident_per_cu(Kernel kernel, int threads, size_t lds, const char *
 }
 template <bool kMatch>
 unsigned jl_build_grid(unsigned parts, const DeviceInfo &dev) {
-  static const unsigned per_cu = jl_resident_per_cu(jl_build_kernel<kMatch>, kJlBuildThreads, jl_build_lds_bytes(),
+  static const unsigned per_cu = jl_resident_per_cu(jl_build_kernel<kMatch, false>, kJlBuildThreads, jl_build_lds_bytes(),
                                                     kMatch ? "DBHIP_JL_MATCH_WGS" : "DBHIP_JL_BUILD_WGS", 3u);
   const size_t cap = static_cast<size_t>(dev.cus) * per_cu;
   return static_cast<unsigned>(parts < cap ? parts : cap);
@@ -1769,7 +1941,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
   const int rc = jl_partition_rows(build_keys, row_ids, n, workspace, s, dev, L, &p);
   if (rc != 0) return rc;
   const size_t build_lds = jl_build_lds_bytes();
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<false>),
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<false, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
   // giant partitions (join_common.hpp): listed by the build kernel, counted and filled by two launches of their own
@@ -1781,15 +1953,27 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
     const hipError_t eg = fill_async(giants.base, 0, jl_giant_header_bytes(L.max_giants), s);
     if (eg != hipSuccess) return static_cast<int>(eg);
   }
-  hipLaunchKernelGGL(jl_build_kernel<false>, dim3(jl_build_grid<false>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, p.keys,
-                     p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
-                     JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, giants);
-  if (giants.max) {
+  // spilled partitions (more distinct keys than a sub-table has slots): from the size where the giants' launches exist
+  // they are listed and built at the end of jl_giant_ids_kernel; below it the build kernel's workgroup does it at once
+  const JlSpill spill = jl_spill_of(static_cast<char *>(workspace) + L.spill_off, L.parts, n);
+  const JlMatchArgs no_match{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (L.max_giants) {
+    hipLaunchKernelGGL((jl_build_kernel<false, false>), dim3(jl_build_grid<false>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s,
+                       p.keys, p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
+                       no_match, giants, spill.area);
     const unsigned grid = static_cast<unsigned>(dev.cus) * (2048 / kJlGiantThreads);
-    hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
-                       p.starts, p.table, jl_pos_bits(n), giants, p.status);
+    if (giants.max)
+      hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
+                         p.starts, p.table, jl_pos_bits(n), giants, p.status, spill);
     hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(p.keys),
-                       p.starts, p.table, giants, ids, p.status, JlMatchArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, 0u);
+                       p.starts, p.table, giants, ids, p.status, no_match, jl_pos_bits(n), spill);
+  } else {
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+    if (e2 != hipSuccess) return static_cast<int>(e2);
+    hipLaunchKernelGGL((jl_build_kernel<false, true>), dim3(jl_build_grid<false>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s,
+                       p.keys, p.rids, p.starts, p.table, L.parts, static_cast<unsigned>(n), jl_pos_bits(n), ids, p.status,
+                       no_match, giants, spill.area);
   }
   return launch_status();
 }
@@ -1799,7 +1983,7 @@ int join_lds_build(const unsigned *build_keys, const unsigned *row_ids, size_t n
 namespace {
 struct JrLayout {
   unsigned parts, k1, k2, log2_k2, max_giants;
-  size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, giant_off, total;
+  size_t meta_bytes, b_a, b_b, b_meta, p_a, p_b, p_meta, giant_off, spill_off, total;
 };
 JrLayout jr_layout(size_t n_build, size_t n_probe) {
   const JlLayout G = jl_layout(n_build, kJrRowsPerPart);
@@ -1816,7 +2000,8 @@ JrLayout jr_layout(size_t n_build, size_t n_probe) {
   L.p_meta = L.p_b + (L.k2 > 1 ? cp : 0);
   L.max_giants = jr_max_giants(n_build, n_probe);
   L.giant_off = L.p_meta + mb;
-  L.total = align_up(L.giant_off + jl_giant_bytes(L.max_giants, true), kWsAlign);
+  L.spill_off = align_up(L.giant_off + jl_giant_bytes(L.max_giants, true), kWsAlign);
+  L.total = L.spill_off + jl_spill_bytes(L.parts, n_build);
   return L;
 }
 // where a partitioned side ended up is a pure function of the sizes: no state is kept between the calls
@@ -1858,8 +2043,11 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
   jr_side(L, base, false, &bp, &bs);
   jr_side(L, base, true, &pp, &ps);
   const size_t build_lds = jl_build_lds_bytes();
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<true, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(build_lds));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(jl_build_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(build_lds));
   if (e != hipSuccess) return static_cast<int>(e);
   // partitions with a giant build OR probe side (join_common.hpp): left out by the fused kernel, listed, then built into
   // scratch sub-tables (jl_giant_count / jl_giant_ids) and probed (second half of jl_giant_ids) by all workgroups together
@@ -1875,15 +2063,21 @@ int join_radix_match(size_t n_build, size_t n_probe, unsigned *ids, unsigned *ou
   }
   const JlMatchArgs match{reinterpret_cast<const u32x2 *>(pp), ps, out_rid, out_pos, out_cnt};
   unsigned *status = reinterpret_cast<unsigned *>(base);
-  hipLaunchKernelGGL(jl_build_kernel<true>, dim3(jl_build_grid<true>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
-                     static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
-                     static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, status, match, giants);
-  if (giants.max) {
+  const JlSpill spill = jl_spill_of(base + L.spill_off, L.parts, n_build);
+  if (L.max_giants) {
+    hipLaunchKernelGGL((jl_build_kernel<true, false>), dim3(jl_build_grid<true>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
+                       static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
+                       static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, status, match, giants, spill.area);
     const unsigned grid = static_cast<unsigned>(dev.cus) * (2048 / kJlGiantThreads);
-    hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
-                       static_cast<u32x2 *>(nullptr), jl_pos_bits(n_build), giants, status);
+    if (giants.max)
+      hipLaunchKernelGGL(jl_giant_count_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
+                         static_cast<u32x2 *>(nullptr), jl_pos_bits(n_build), giants, status, spill);
     hipLaunchKernelGGL(jl_giant_ids_kernel, dim3(grid), dim3(kJlGiantThreads), 0, s, reinterpret_cast<const u32x2 *>(bp), bs,
-                       static_cast<u32x2 *>(nullptr), giants, ids, status, match, jl_pos_bits(n_build));
+                       static_cast<u32x2 *>(nullptr), giants, ids, status, match, jl_pos_bits(n_build), spill);
+  } else {
+    hipLaunchKernelGGL((jl_build_kernel<true, true>), dim3(jl_build_grid<true>(L.parts, dev)), dim3(kJlBuildThreads), build_lds, s, bp,
+                       static_cast<const unsigned *>(nullptr), bs, static_cast<u32x2 *>(nullptr), L.parts,
+                       static_cast<unsigned>(n_build), jl_pos_bits(n_build), ids, status, match, giants, spill.area);
   }
   return launch_status();
 }
@@ -1905,7 +2099,8 @@ int ujoin_lds_probe(const unsigned *probe_keys, const unsigned *probe_vals, size
                     const DeviceInfo &dev) {
   const JlLayout L = jl_layout(n_build);
   const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
-  hipLaunchKernelGGL(jl_uprobe_kernel, dim3(jl_grid(n_probe, dev, 8)), dim3(kJlThreads), 0, s, probe_keys, probe_vals,
+  static const int uprobe_wgs = static_cast<int>(jl_resident_per_cu(jl_uprobe_kernel, kJlThreads, 0, "DBHIP_JL_UPROBE_WGS", 4u));
+  hipLaunchKernelGGL(jl_uprobe_kernel, dim3(jl_grid(n_probe, dev, uprobe_wgs)), dim3(kJlThreads), 0, s, probe_keys, probe_vals,
                      n_probe, table, L.parts, out_key, out_bval, out_pval);
   return launch_status();
 }
@@ -1914,13 +2109,14 @@ int join_lds_probe(const unsigned *probe_keys, size_t n_probe, const void *works
                    unsigned *out_pos, unsigned *out_cnt, hipStream_t s, const DeviceInfo &dev) {
   const JlLayout L = jl_layout(n_build);
   const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
-  static const int wgs_per_cu = [] {
-    const char *e = getenv("DBHIP_JL_PROBE_WGS");  // experiment knob: workgroups per CU of the probe grid
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 64 ? v : 8;
-  }();
+  // Exactly the workgroups that are resident (four of 512 threads per CU), every thread striding over its rows: with
+  // eight per CU — two rounds of workgroups — the kernel's time depended on how the second round happened to fill in
+  // (round 4, same box, 2^26 rows: 2 per CU 1767-1838 us, 4: 1553-1572, 6: 1692-1713, 8: 1566 for one build of this
+  // kernel and 1708 for another whose loop was the same instructions; 16: 1566 / 1625).  DBHIP_JL_PROBE_WGS: experiments.
+  static const int wgs_per_cu = static_cast<int>(jl_resident_per_cu(jl_probe_kernel, kJlThreads, 0, "DBHIP_JL_PROBE_WGS", 4u));
+  char *ws = const_cast<char *>(static_cast<const char *>(workspace));
   hipLaunchKernelGGL(jl_probe_kernel, dim3(jl_grid(n_probe, dev, wgs_per_cu)), dim3(kJlThreads), 0, s, probe_keys, n_probe,
-                     table, L.parts, jl_pos_bits(n_build), out_pos, out_cnt);
+                     table, L.parts, jl_pos_bits(n_build), out_pos, out_cnt, jl_spill_of(ws + L.spill_off, L.parts, n_build));
   return launch_status();
 }
 

@@ -195,18 +195,86 @@ def test_join_build_with_giant_partitions(kind, n):
     _check_grouped_join(build, probe)
 
 
-def test_a_giant_partition_with_too_many_keys_is_flagged():
-    """more than 3072 distinct keys in one partition: TABLE_FULL, as in the per-partition build — and no stray store"""
-    from dwarf_bench_amd import _capi, ops
-    n = 1 << 18
+def _keys_of_partition_of(parts, partition, how_many):
+    cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
+    mine = cand[(_fmix32(cand) * parts) >> 32 == partition][:how_many]
+    assert mine.size == how_many
+    return mine.astype(np.uint32)
+
+
+def _radix_parts(n_build):
+    """partitions of the radix join (join_common.hpp jl_layout with kJrRowsPerPart = 1792 rows per partition)"""
+    want = min(max(1, -(-n_build // 1792)), 1 << 20)
+    lg = (want - 1).bit_length()
+    if want <= 1024:
+        k2 = 1
+    else:
+        lgs = lg - 1 if (1 << lg) != want else lg
+        k2 = 1 << (lgs // 2)
+    k1 = -(-want // k2)
+    while k1 > 1024:
+        k2 *= 2
+        k1 = -(-want // k2)
+    return k1 * k2
+
+
+SPILL_SHAPES = [  # (build rows, distinct keys put into ONE partition, rows per key): more keys than the 3072 slots of a sub-table
+    (1 << 16, 3500, 1),    # below 2^18 rows the build kernel's workgroup builds the spill table itself
+    (1 << 16, 4000, 9),
+    (1 << 18, 3500, 1),    # listed by the build kernel, built at the end of jl_giant_ids
+    (1 << 18, 3500, 20),   # 70000 rows: a giant partition — jl_giant_count finds its sub-table full and lists it
+    (1 << 20, 9000, 5),    # two scatter levels; a giant whose single slices overflow the LDS sub-table
+    (1 << 18, 40000, 1),   # a partition of 40000 distinct keys
+]
+
+
+@pytest.mark.parametrize("n,keys,per_key", SPILL_SHAPES)
+def test_a_partition_with_more_distinct_keys_than_slots_joins_like_any_other(n, keys, per_key):
+    """The reference's table takes any keys (ht_size = 2 * distinct, join/join_omnisci.cpp:69-70; linear probing until a
+    slot is found, omnisci_hashtable.hpp:80-108).  A partition of the LDS join holds at most 3072 DISTINCT keys in its
+    sub-table; keys constructed against the partition hash go beyond that: such a partition is built in an
+    open-addressing table of its own in HBM (jl_spill_partition) and the join's results are what they are for any other
+    input — counts per probe row, ids grouped by key, status 0 (until round 4 this raised DBHIP_DEV_TABLE_FULL)."""
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(31)
     build = po.gen_uniform_u32(n, 42, 0, n - 1)
-    build[: 3500 * 20] = np.repeat(_keys_of_partition(n, 1, 3500), 20)
+    mine = _keys_of_partition(n, 1, keys)
+    build[: keys * per_key] = np.repeat(mine, per_key)
+    build = rng.permutation(build)
+    probe = po.gen_uniform_u32(1 << 16, 43, 0, n - 1)
+    probe[::3] = mine[rng.integers(0, keys, probe[::3].size)]          # hits in the spilled partition
+    probe[1::11] = _keys_of_partition(n, 1, keys + 500)[keys:][rng.integers(0, 500, probe[1::11].size)]  # and misses there
+    _check_grouped_join(build, probe)
     plan = ops.HashJoin(n, 16)
     plan.build(_dev(build))
     plan.probe(_dev(build[:16]))
-    assert ops.workspace_status(plan.ws) & ops.DEV_TABLE_FULL
-    with pytest.raises(_capi.DbhipError):
-        plan.result()
+    assert ops.workspace_status(plan.ws) == 0
+    plan.build(_dev(po.gen_uniform_u32(n, 44, 0, n - 1)))  # the same plan on ordinary keys afterwards: nothing left behind
+    plan.probe(_dev(build[:16]))
+    assert ops.workspace_status(plan.ws) == 0
+
+
+@pytest.mark.parametrize("n,keys,per_key", SPILL_SHAPES)
+def test_radix_join_of_a_partition_with_more_distinct_keys_than_slots(n, keys, per_key):
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(37)
+    parts = _radix_parts(n)
+    ha = po.gen_uniform_u32(n, 42, 0, n - 1)
+    mine = _keys_of_partition_of(parts, parts // 3, keys + 300)
+    ha[: keys * per_key] = np.repeat(mine[:keys], per_key)
+    ha = rng.permutation(ha)
+    npr = (1 << 17) + 77
+    hb = po.gen_uniform_u32(npr, 43, 0, n - 1)
+    hb[::3] = mine[rng.integers(0, keys + 300, hb[::3].size)]  # hits and misses inside the spilled partition
+    rid, pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.radix_join(_dev(ha), _dev(hb)))
+    assert np.array_equal(np.sort(rid), np.arange(npr, dtype=np.uint32))
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    assert np.array_equal(cnt, po.join_counts_fast(ha, hb).astype(np.uint32)[rid])
+    in_order = ha[ids]
+    assert np.count_nonzero(in_order[1:] != in_order[:-1]) + 1 == np.unique(ha).size  # every key's ids are one run
+    hit = cnt > 0
+    assert np.array_equal(in_order[pos[hit]], hb[rid[hit]])
+    assert np.array_equal(in_order[pos[hit] + cnt[hit] - 1], hb[rid[hit]])
 
 
 def test_join_a_few_rows_above_2_27_through_the_packed_histogram():
