@@ -70,7 +70,7 @@ def test_cli_list_and_exit_codes():
     names = [l.strip() for l in r.stdout.splitlines() if l.startswith("\t")]
     assert names == sorted(["DPLScanHip", "GroupByHip", "GroupByLocalHip", "HashBuildHip", "HashBuildNonBitmaskHip", "JoinHip",
                             "JoinOmnisciHip", "NestedLoopJoinHip", "PartitionedJoinHip", "ProbeHip", "RadixHip", "ReduceHip",
-                            "TwoPassScanHip"])
+                            "TBBSort", "TwoPassScan", "TwoPassScanHip"])
     assert "DWARF_BENCH_ROOT is set to" in r.stdout
     r = subprocess.run([str(exe), "NoSuchDwarf"], capture_output=True, text=True)
     assert r.returncode == 1 and "List supported dwarfs" in r.stderr  # main.cpp:75-79
@@ -86,3 +86,36 @@ def test_reference_usage_example_compiles_against_our_header():
     """example/bench_usage/main.cpp:4-33 must compile unchanged against this build's <bench.hpp>."""
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(HOST), "/root/reference/example/bench_usage/main.cpp"],
                    check=True)
+
+
+def test_baseline_config_1_as_written_runs_on_the_host(tmp_path):
+    """BASELINE.json configs[0], verbatim: `TwoPassScan --device=cpu --input_size=1024 --iterations=9` — nine valid
+    Results and the reference's CSV (scan/scan.cpp:184-195, common/result.cpp:59-91).  The host dwarf needs no GPU."""
+    exe = _cli()
+    path = tmp_path / "scan.csv"
+    r = subprocess.run([str(exe), "TwoPassScan", "--device=cpu", "--input_size=1024", "--iterations=9", "--report_path", str(path)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "incorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    lines = path.read_text().splitlines()
+    assert lines[0] == "device_type,buf_size_bytes,host_time_ms,kernel_time_ms"
+    assert len(lines) == 10 and all(l.startswith("CPU,4096,") for l in lines[1:])
+    r = subprocess.run([str(exe), "TwoPassScan", "--device=cpu", "--input_size=1024", "--iterations=9"], capture_output=True, text=True,
+                       timeout=120)  # without a report path the averaged Result is printed (common/result.cpp:5-18)
+    assert r.returncode == 0 and r.stdout.count("Kernel duration:") == 1 and r.stdout.count("Host duration:") == 1
+
+
+def test_host_dwarfs_on_ragged_sizes_and_the_wrong_device(tmp_path):
+    """TwoPassScan / TBBSort (sort/tbbsort.cpp:15-48, SURVEY row a8) validate every iteration against std::copy_if /
+    std::sort: sizes that are not a multiple of the thread count (the reference kernel drops that tail, ours does
+    not), an empty column, several sizes in one run; asked for --device=hip they throw like the reference's device
+    selection does for a type it does not serve (caught by main: exit code 0, main.cpp:97-100)."""
+    exe = _cli()
+    for dwarf in ("TwoPassScan", "TBBSort"):
+        path = tmp_path / f"{dwarf}.csv"
+        r = subprocess.run([str(exe), dwarf, "--device", "cpu", "--input_size", "0", "1", "1000003", "262144", "--iterations", "3",
+                            "--report_path", str(path)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "incorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+        sizes = [l.split(",")[1] for l in path.read_text().splitlines()[1:]]
+        assert sizes == ["0"] * 3 + ["4"] * 3 + [str(4 * 1000003)] * 3 + [str(4 * 262144)] * 3
+        r = subprocess.run([str(exe), dwarf, "--device", "hip", "--input_size", "1024"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "is the host dwarf" in r.stderr
