@@ -392,6 +392,7 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
             dist.barrier()
         torch.cuda.synchronize()
 
+    info = eng.info()
     last = None
     for _ in range(max(1, warmup)):
         last = eng.step()
@@ -414,6 +415,15 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     w = [int(x) for x in words.cpu().tolist()]
     n_ranks = world if multi else 1
+    # what RCCL itself reports (ncclCommCount on every rank's communicator: the smallest answer over the ranks) and the GPU
+    # every rank ran on — so that "the exchange ran over N ranks on N GPUs" can be read off the line
+    seen = torch.tensor([info["rccl_ranks_seen"]], dtype=torch.int64, device="cuda")
+    devices = [f"rank {rank}: cuda:{info['device']} {info['device_name']}"]
+    if multi:
+        dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+        box = [None] * world
+        dist.all_gather_object(box, devices[0])
+        devices = box
     exchange = None
     if multi and last:
         # what the first real multi-GPU line needs to be readable: bytes per xGMI link and the rate the two send/recv
@@ -426,7 +436,7 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
             us = last.get(f"exchange_{rel}_us") or 0.0
             exchange[f"exchange_{rel}_us"] = round(us, 1)
             exchange[f"achieved_gbs_per_link_{rel}"] = (link_bytes / us / 1e3) if us > 0 else None
-    return {"rows": 2 * total, "exchange_links": exchange, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
+    return {"rows": 2 * total, "rccl_ranks_seen": int(seen.item()), "rank_devices": devices, "exchange_links": exchange, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
             "rows_exchanged": w[4], "bytes_sent_per_gpu": w[4] * 8 / n_ranks,
             "max_over_mean_rows_per_rank": float(mx[5]) * n_ranks / max(w[5], 1),
             "checks": {"damaged_pairs": w[0], "misrouted_keys": w[1], "wrong_probe_rows": w[2],

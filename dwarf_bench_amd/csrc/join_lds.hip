@@ -2,31 +2,32 @@
 // LDS-resident sub-tables, single-gather probe.  OmniSci semantics: distinct-key table, per-key count, exclusive scan -> position, ids grouped by key, probe ->
 // {offset, count} (common/dpcpp/omnisci_hashtable.hpp:58-261).
 //
-// Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench)
-// — three per build row — and three 4-byte gathers per probe row (53 G/s).  LDS atomics run at
-// > 800 G/s.  So:
+// Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench) — three per
+// build row — and three 4-byte gathers per probe row (53 G/s).  Random LDS atomics run at ~4,000 G/s chip-wide
+// (profiles/r03_ubench.txt).  So:
 //   build  1. partition the build column into K = ceil(n / 2048) partitions (join_common.hpp jl_layout) by the mixed hash,
-//             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts,
-//             one global reservation per bucket per 4096-key tile, runs of (key, row id) pairs written
-//             contiguously);
-//          2. persistent workgroups walk the partitions (jl_build): 6144-slot sub-table in LDS — ds_cmpst
-//             claim of the key's slot, ds_add count, LDS exclusive scan -> positions, the fill takes slot and
-//             row id of each row from registers kept since the claim, then the sub-table is written out
-//             as 8-byte slots {key, first id position | count field} — EVERY slot, empty ones included,
-//             carries the position the exclusive scan reached there, and positions run on from one
-//             sub-table to the next (the global table is the concatenation of the sub-tables plus one
-//             sentinel slot {empty, n}), so a key's match count is ALSO first_position[slot + 1] -
-//             first_position[slot]; the bits of the position word that n does not need hold
-//             min(count - 1, all ones) (join_common.hpp): the table costs 12 bytes per build row;
-//   probe  ONE 8-byte gather per probe row whenever the count fits its field (a 16-byte read of slot and
-//          neighbour crossed a 64-byte line for every eighth row: one more memory request); the all-ones
-//          field sends the row to the right-hand neighbour.  Partition from the high hash bits, linear
-//          probing inside the sub-table, outputs written coalesced in row order.
-// A partition may hold any number of rows (duplicates do not matter: one far above its expected size — a hot key — is
-// shared by all workgroups, see "giant partitions" below); it may hold at most DBHIP_JL_SUB_SLOTS
-// (3072) DISTINCT keys — with 2048 rows expected per partition (+-45 per sigma) and a mixing hash that takes keys
-// constructed against the hash; if it happens the build sets DBHIP_DEV_TABLE_FULL (the call fails loudly, there
-// is no second partitioning with another hash).
+//             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts, one global
+//             reservation per bucket per tile, runs of (key, row id) pairs written contiguously; tiles of 4096 rows,
+//             of 16384 where a level has 512+ buckets: JlShape);
+//          2. persistent workgroups — as many as are RESIDENT, partitions dealt by ticket — walk the partitions
+//             (jl_build_kernel): 3072-slot sub-table in LDS (kJlSubSlots) — plain read of the key's slot, ds_cmpst on
+//             an empty one, ONE returning ds_add whose old value is the row's rank inside its key group, LDS exclusive
+//             scan -> positions, the fill takes slot and rank of each row from registers kept since the claim, then
+//             the sub-table is written out as 8-byte slots {key, first id position | count field} — EVERY slot, empty
+//             ones included, carries the position the exclusive scan reached there, and positions run on from one
+//             sub-table to the next (the global table is the concatenation of the sub-tables plus one sentinel slot
+//             {empty, n}), so a key's match count is ALSO first_position[slot + 1] - first_position[slot]; the bits
+//             of the position word that n does not need hold min(count - 1, all ones) (join_common.hpp): the table
+//             costs 12 bytes per build row;
+//   probe  ONE 8-byte gather per probe row whenever the count fits its field (a 16-byte read of slot and neighbour
+//          crossed a 64-byte line for every eighth row: one more memory request); the all-ones field sends the row to
+//          the right-hand neighbour.  Partition from the high hash bits, linear probing inside the sub-table, outputs
+//          written coalesced in row order.
+// A partition may hold any number of rows: one far above its expected size — a hot key — is shared by all workgroups
+// ("giant partitions" below).  It may hold any number of DISTINCT keys too: 2048 +- 45 per sigma are expected, a
+// sub-table has 3072 slots, and a partition that needs more (keys constructed against the hash) is built in a table of
+// its own in HBM by one workgroup (jl_spill_partition; until round 4 this raised DBHIP_DEV_TABLE_FULL) — the join
+// answers every input the reference's table answers (omnisci_hashtable.hpp:80-108, ht_size = 2 * distinct).
 #include "dbhip_common.hpp"
 #include "join_common.hpp"
 

@@ -30,10 +30,23 @@ void nccl_ok(ncclResult_t r, const char *what) {
   if (r != ncclSuccess) fail(std::string(what) + ": " + ncclGetErrorString(r));
 }
 
-// One ncclSend/ncclRecv of 2^29 uint32 (2 GiB) completed without an error and delivered garbage (RCCL 2.27.7, caught
-// by the conservation check); pieces of 2^28 elements (1 GiB) have carried every run since.  Both sides cut a segment
-// the same way, so the k-th piece sent to a peer meets the k-th piece received from it.
-constexpr uint64_t kPiece = 1ull << 28;
+// An ncclSend/ncclRecv pair of MORE than 2^28 uint32 (1 GiB) completes without an error and delivers garbage (RCCL
+// 2.27.7 on ROCm 7.2, one rank sending to itself; caught by the conservation check).  Pinned in round 4 with
+// DWARF_BENCH_PJOIN_PIECE=<elements> on the 2^30-row self-exchange (gpurun_out/exp_piece*.log): pieces of
+// 2^28 elements arrive intact; 2^28 + 1, 3 * 2^27, 2^29 - 1 and 2^29 elements are damaged — and only the pieces above
+// 2^28 elements are (with 3 * 2^27 the two long pieces of a column arrive damaged, its 2^28-element remainder intact).  So
+// it is NOT the signed 32-bit byte count at 2^31 bytes that VERDICT r03 suspected (2^29 - 1 elements = 2^31 - 4 bytes
+// fail as well): the limit is 2^30 BYTES per message.  Pieces are 2^27 elements (512 MiB): half the largest size seen
+// to work.  Both sides cut a segment the same way, so the k-th piece sent to a peer meets the k-th piece received from it.
+constexpr uint64_t kPiece = 1ull << 27;
+uint64_t piece_elems() {
+  static const uint64_t v = [] {
+    const char *e = std::getenv("DWARF_BENCH_PJOIN_PIECE");
+    const unsigned long long want = e ? std::strtoull(e, nullptr, 10) : 0ull;
+    return want ? static_cast<uint64_t>(want) : kPiece;
+  }();
+  return v;
+}
 
 struct DevMem {  // hipMalloc on a given device; grows, never shrinks
   int dev = 0;
@@ -257,15 +270,16 @@ struct Engine::Impl {
         if (send_off + send_cnt > me.n_local || recv_off + recv_cnt > recv_total || recv_total > recv_cap)
           fail("partitioned join: exchange segment outside its buffer");
         static_assert(kPiece <= (1ull << 28), "one ncclSend/ncclRecv carries at most 2^28 elements (1 GiB)");
+        const uint64_t piece = piece_elems();
         if (rccl) {
           for (int col = 0; col < 2; ++col) {
             const uint32_t *s = (col ? src_r : src_k) + send_off;
             uint32_t *d = (col ? dst_r : dst_k) + recv_off;
-            for (uint64_t o = 0; o < send_cnt; o += kPiece)
-              nccl_ok(ncclSend(s + o, std::min(kPiece, send_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
+            for (uint64_t o = 0; o < send_cnt; o += piece)
+              nccl_ok(ncclSend(s + o, std::min(piece, send_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
                       "ncclSend");
-            for (uint64_t o = 0; o < recv_cnt; o += kPiece)
-              nccl_ok(ncclRecv(d + o, std::min(kPiece, recv_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
+            for (uint64_t o = 0; o < recv_cnt; o += piece)
+              nccl_ok(ncclRecv(d + o, std::min(piece, recv_cnt - o), ncclUint32, static_cast<int>(q), me.comm, me.xchg),
                       "ncclRecv");
           }
         } else if (send_cnt) {  // push into the peer's receive buffers (the peer is a local rank in this mode)
@@ -386,6 +400,13 @@ Engine::~Engine() {
 unsigned Engine::world() const { return impl_->P; }
 unsigned Engine::local_ranks() const { return static_cast<unsigned>(impl_->ranks.size()); }
 bool Engine::uses_rccl() const { return impl_->rccl; }
+unsigned Engine::rccl_ranks_seen() const {
+  if (!impl_->rccl || impl_->ranks.empty() || !impl_->ranks[0]->comm) return 0;
+  int count = 0;
+  if (ncclCommCount(impl_->ranks[0]->comm, &count) != ncclSuccess || count < 0) return 0;
+  return static_cast<unsigned>(count);
+}
+int Engine::device_of(unsigned i) const { return impl_->local(i).device; }
 size_t Engine::n_total() const { return impl_->n; }
 
 void Engine::plan() {
@@ -752,17 +773,44 @@ extern "C" void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned w
   }
 }
 
-extern "C" int dbench_pjoin_step(void *handle, double *times_us) {
+extern "C" int dbench_pjoin_step_n(void *handle, double *times_us, unsigned capacity) {
   if (!handle) return -1;
   try {
     const pjoin::StepTimes t = static_cast<pjoin::Engine *>(handle)->step();
-    if (times_us) {
-      const double v[8] = {t.total, t.partition, t.exchange, t.build, t.probe, t.until_build_done, t.exchange_r, t.exchange_s};
-      std::memcpy(times_us, v, sizeof(v));
+    const double v[8] = {t.total, t.partition, t.exchange, t.build, t.probe, t.until_build_done, t.exchange_r, t.exchange_s};
+    const unsigned k = capacity < 8u ? capacity : 8u;
+    if (times_us && k) std::memcpy(times_us, v, k * sizeof(double));
+    return static_cast<int>(k);
+  } catch (const std::exception &ex) {
+    std::cerr << "dbench_pjoin_step: " << ex.what() << std::endl;
+    return -2;
+  }
+}
+// (the first form of this call, kept with its six values: a caller built against `double t[6]` stays inside its array)
+extern "C" int dbench_pjoin_step(void *handle, double *times_us) {
+  const int rc = dbench_pjoin_step_n(handle, times_us, times_us ? 6u : 0u);
+  return rc < 0 ? rc : 0;
+}
+
+extern "C" int dbench_pjoin_info(void *handle, unsigned *words, char *name, unsigned long len) {
+  if (!handle || !words) return -1;
+  try {
+    auto *e = static_cast<pjoin::Engine *>(handle);
+    words[0] = e->rccl_ranks_seen();
+    words[1] = e->world();
+    words[2] = static_cast<unsigned>(e->device_of(0));
+    words[3] = e->local_ranks();
+    if (name && len) {
+      name[0] = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, e->device_of(0)) == hipSuccess) {
+        std::strncpy(name, prop.name, len - 1);
+        name[len - 1] = 0;
+      }
     }
     return 0;
   } catch (const std::exception &ex) {
-    std::cerr << "dbench_pjoin_step: " << ex.what() << std::endl;
+    std::cerr << "dbench_pjoin_info: " << ex.what() << std::endl;
     return -2;
   }
 }

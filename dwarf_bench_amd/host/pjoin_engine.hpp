@@ -76,6 +76,10 @@ class Engine {
   unsigned world() const;
   unsigned local_ranks() const;
   bool uses_rccl() const;
+  // ranks RCCL itself reports for the first local rank's communicator (ncclCommCount; 0 without RCCL): what a reader of
+  // a multi-GPU bench line needs to see that the exchange really ran over `world` ranks
+  unsigned rccl_ranks_seen() const;
+  int device_of(unsigned local_index) const;
   size_t n_total() const;
   // host copies of one local rank's results (validation of small runs)
   struct HostShard {
@@ -99,8 +103,13 @@ int dbench_pjoin_unique_id(char *out128);
 // every rank: device = local GPU index.  world == 1 needs no id.  Returns a handle or NULL (message on stderr).
 void *dbench_pjoin_create(uint64_t n_total, unsigned rank, unsigned world, int device, const char *id128,
                           int direct_single);
-// one join; times_us[8] = total, partition, exchange, build, probe, until_build_done, exchange_r, exchange_s.  0 on success.
+// one join; times_us[6] = total, partition, exchange, build, probe, until_build_done.  0 on success.
 int dbench_pjoin_step(void *handle, double *times_us);
+// the same with the caller's capacity: up to 8 values (..., exchange_r, exchange_s); returns the number written (> 0) or < 0
+int dbench_pjoin_step_n(void *handle, double *times_us, unsigned capacity);
+// words[4] = ranks RCCL reports for this rank's communicator (ncclCommCount; 0 = no RCCL), world, this rank's HIP device,
+// local ranks; name (<= len bytes) = that device's name.  0 on success.
+int dbench_pjoin_info(void *handle, unsigned *words, char *name, unsigned long len);
 // after a step; words[16]: bad_pairs, bad_route, bad_rows, matches, recv_build, recv_probe, sent_rows,
 // conserved (over ALL ranks: collective call), sent_sum[4], recv_sum[4].  0 on success.
 int dbench_pjoin_check(void *handle, uint64_t *words);

@@ -77,14 +77,14 @@ class PartitionedJoinResult:
 
 
 # Largest single message (one peer's segment of one column) the exchange hands to the backend, in ELEMENTS.
-# What is known: one ncclSend/ncclRecv pair of exactly 2^29 uint32 (2 GiB) through RCCL 2.27.7 completed without
-# an error and delivered garbage (PartitionedJoinHip --gpus 1 at 2^30 rows, caught by its conservation check);
-# pieces of 2^28 elements (1 GiB) have carried every run since.  The cause inside RCCL was not established — a
-# byte count that no longer fits 31 bits is the obvious suspect — so the bound is set where the evidence is:
-# no message above 1 GiB.  A hash bucket of 2^30 rows over 2 ranks holds 2^28 +- ~12K rows, i.e. about half of
-# them are just above 1 GiB: such a segment goes out in two rounds.  Both sides derive the rounds from the same
-# split sizes, so the r-th piece sent to a peer meets the r-th piece received from it.
-MAX_MESSAGE_ELEMS = 1 << 28
+# An ncclSend/ncclRecv pair of more than 2^28 uint32 (1 GiB) through RCCL 2.27.7 completes without an error and delivers
+# garbage (PartitionedJoinHip --gpus 1 at 2^30 rows, caught by its conservation check).  Round 4 pinned the limit with the
+# C++ engine's DWARF_BENCH_PJOIN_PIECE knob (host/pjoin_engine.cpp): 2^28 elements intact; 2^28 + 1, 3 * 2^27, 2^29 - 1
+# and 2^29 damaged, and only the pieces above 2^28 — 2^30 BYTES per message is the limit, not the signed 32-bit byte
+# count at 2^31.  Messages here are at most 2^27 elements (512 MiB), half the largest size seen to work.  A hash bucket
+# of 2^30 rows over 2 ranks holds 2^28 +- ~12K rows: such a segment goes out in three rounds.  Both sides derive the
+# rounds from the same split sizes, so the r-th piece sent to a peer meets the r-th piece received from it.
+MAX_MESSAGE_ELEMS = 1 << 27
 
 
 class _Done:

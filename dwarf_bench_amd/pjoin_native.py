@@ -28,8 +28,10 @@ def lib() -> C.CDLL:
         h.dbench_pjoin_unique_id.argtypes = [C.c_char_p]
         h.dbench_pjoin_create.restype = C.c_void_p
         h.dbench_pjoin_create.argtypes = [C.c_uint64, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_int]
-        h.dbench_pjoin_step.restype = C.c_int
-        h.dbench_pjoin_step.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        h.dbench_pjoin_step_n.restype = C.c_int
+        h.dbench_pjoin_step_n.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint]
+        h.dbench_pjoin_info.restype = C.c_int
+        h.dbench_pjoin_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_char_p, C.c_ulong]
         h.dbench_pjoin_check.restype = C.c_int
         h.dbench_pjoin_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         h.dbench_pjoin_destroy.restype = None
@@ -60,9 +62,19 @@ class NativePartitionedJoin:
 
     def step(self) -> dict:
         t = (C.c_double * len(STEP_FIELDS))()
-        if lib().dbench_pjoin_step(self._h, t) != 0:
-            raise _capi.DbhipError("dbench_pjoin_step failed (see stderr)")
-        return dict(zip(STEP_FIELDS, (float(x) for x in t)))
+        got = lib().dbench_pjoin_step_n(self._h, t, len(STEP_FIELDS))
+        if got <= 0:
+            raise _capi.DbhipError("dbench_pjoin_step_n failed (see stderr)")
+        return dict(zip(STEP_FIELDS[:got], (float(x) for x in t[:got])))
+
+    def info(self) -> dict:
+        """what RCCL itself says about this rank's communicator (ncclCommCount) and the GPU the rank runs on"""
+        w = (C.c_uint * 4)()
+        name = C.create_string_buffer(256)
+        if lib().dbench_pjoin_info(self._h, w, name, 256) != 0:
+            raise _capi.DbhipError("dbench_pjoin_info failed (see stderr)")
+        return {"rccl_ranks_seen": int(w[0]), "world": int(w[1]), "device": int(w[2]), "local_ranks": int(w[3]),
+                "device_name": name.value.decode(errors="replace")}
 
     def check(self) -> dict:
         """device-side checks of the last step (collective over all ranks of the join)"""

@@ -182,8 +182,9 @@ def test_scan_host_time_with_transfers(tmp_path):
 
 
 def test_partitioned_join_rccl_messages_above_one_gib():
-    """n = 2^28 + 12345 rows through --gpus 1: the rank's RCCL self send/recv carries every column (> 1 GiB) as two
-    pieces of at most 2^28 elements.  A single 2 GiB ncclSend/ncclRecv once delivered garbage without an error: the
+    """n = 2^28 + 12345 rows through --gpus 1: the rank's RCCL self send/recv carries every column (> 1 GiB) as three
+    pieces of at most 2^27 elements.  A single ncclSend/ncclRecv above 1 GiB delivers garbage without an error (RCCL
+    2.27.7; pinned in round 4, host/pjoin_engine.cpp kPiece): the
     always-on conservation check and the device-side pair / routing / count checks must stay silent.  The log is
     kept under gpurun_out/ (a copy is committed under profiles/)."""
     r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", "1", "--iterations", "1", "--input_size", "268447801"])
@@ -242,7 +243,7 @@ def test_partitioned_join_baseline_config_5(gpus, tag, extra_env):
     rank partitions, exchanges and joins its 2^27-row shards — the per-rank work of the 8-GPU node, peer copies in
     place of xGMI), --gpus 1 with DWARF_BENCH_PJOIN_DIRECT=1 is the one-GPU point of the scaling curve (plain local radix
     join), --gpus 1 without it sends all 2^30 pairs of both relations through the RCCL send/recv group to the rank
-    itself (four pieces of 2^28 elements per column).  Host-side checks are off
+    itself (eight pieces of 2^27 elements per column).  Host-side checks are off
     (DWARF_BENCH_VALIDATE_MAX=1): Result::valid rests on the device-side checks (conservation, generator, routing,
     per-row counts against the sorted build column).  The log is kept under gpurun_out/ (copies under profiles/)."""
     import os

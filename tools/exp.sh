@@ -1,10 +1,11 @@
 #!/bin/bash
 set -uo pipefail
 repo="$(pwd)"; mkdir -p gpurun_out; export TMPDIR=/tmp
-out=gpurun_out/exp.log; : > $out
-for w in 2 4 6 8 16; do for v in default prev; do
-  lib=$repo/dwarf_bench_amd/_lib/libdbhip.so; [ $v = prev ] && lib=$repo/dwarf_bench_amd/_lib/variants/libdbhip_prev.so
-  echo "-- PROBE_WGS=$w $v" >> $out
-  DBHIP_LIB=$lib DBHIP_JL_PROBE_WGS=$w timeout -k 10 300 python tools/ab.py join 26 2>&1 | grep -v amdgpu.ids | sed 's/| radix.*//' >> $out
-done; done
+out=gpurun_out/exp_piece2.log; : > $out
+cli=dwarf_bench_amd/_lib/dwarf_bench
+for piece in 268435457 402653184; do
+  echo "== DWARF_BENCH_PJOIN_PIECE=$piece (one rank, all 2^30 pairs of both relations through its own ncclSend/ncclRecv group)" >> $out
+  DWARF_BENCH_PJOIN_PIECE=$piece DWARF_BENCH_VALIDATE_MAX=1 timeout -k 10 300 $cli PartitionedJoinHip --device=hip --gpus 1 --iterations 2 --input_size 1073741824 >> $out 2>&1
+  echo "exit code $?" >> $out
+done
 cat $out
