@@ -290,6 +290,13 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
   const size_t base0 = static_cast<size_t>(slot) * THREADS * kGbVecPerIter;
 #if DBHIP_GB_PIPE
   u32x4 ka[kGbVecPerIter], va[kGbVecPerIter], kb[kGbVecPerIter], vb[kGbVecPerIter];
+  // (Round 4, measured and removed: the row steps of a one-range table handed out by TICKET — batches of four steps, the
+  //  next batch asked for one batch ahead by thread 0 and passed round through the workgroup's own partial-table slot in
+  //  global memory, since the packed table leaves no LDS word free.  Same box, 2^26 rows, three interleaved runs: 65536
+  //  groups 116.0-117.3 us against 115.8-116.8 static; 32768 groups 106.5-108.9 against 105.3-107.0; 1024 groups 101.5-102.1
+  //  against 95.6-97.9; 64 groups 100.3-101.8 against 92.9-98.7.  What ticketing gave the join's build kernels — workgroups
+  //  that are not equally fast — is not what this stream loses time to.)
+  {
   if (base0 < n4) load_step(base0, ka, va);
   for (size_t base = base0; base < n4; base += 2 * step) {
     const bool has_b = base + step < n4;
@@ -298,6 +305,7 @@ __device__ __forceinline__ void gb_aggregate_body(const u32x4 *__restrict__ keys
     if (!has_b) break;
     if (base + 2 * step < n4) load_step(base + 2 * step, ka, va);
     add_step(base + step, kb, vb);
+  }
   }
 #else
   for (size_t base = base0; base < n4; base += step) {

@@ -121,6 +121,10 @@ constexpr unsigned kJlFusedMaxParts = DBHIP_JL_FUSED_MAX_PARTS;  // 0 disables t
 // two 16-bit counters per LDS word (jl_hist_fused16_kernel): as many partitions as the CU's 160 KiB hold — 2^27 rows
 // and a quarter more (a rank of the 8-GPU join receives 2^27 rows +- a few thousand: 65537+ partitions)
 constexpr unsigned kJlFused16MaxParts = 80 * 1024;
+#ifndef DBHIP_JL_HIST_LOADS
+#define DBHIP_JL_HIST_LOADS 4
+#endif
+constexpr int kJlHistLoads = DBHIP_JL_HIST_LOADS;  // 16-byte key loads in flight per lane of the fused16 histogram
 
 __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused_kernel(const unsigned *__restrict__ keys, size_t n, size_t group_rows,
                                                                         unsigned parts, unsigned *__restrict__ wgcnt) {
@@ -209,13 +213,13 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const 
   if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
     const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
     const size_t n4 = (hi - lo) / 4;
-    for (size_t i = static_cast<size_t>(w) * 4 * kJlFusedThreads + threadIdx.x; i < n4;
-         i += static_cast<size_t>(kJlFusedWgPerGroup) * 4 * kJlFusedThreads) {
-      u32x4 v[4];
+    for (size_t i = static_cast<size_t>(w) * kJlHistLoads * kJlFusedThreads + threadIdx.x; i < n4;
+         i += static_cast<size_t>(kJlFusedWgPerGroup) * kJlHistLoads * kJlFusedThreads) {
+      u32x4 v[kJlHistLoads];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = i + j * kJlFusedThreads < n4 ? k4[i + j * kJlFusedThreads] : u32x4{0, 0, 0, 0};
+      for (int j = 0; j < kJlHistLoads; ++j) v[j] = i + j * kJlFusedThreads < n4 ? k4[i + j * kJlFusedThreads] : u32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < kJlHistLoads; ++j)
         if (i + j * kJlFusedThreads < n4) {
           count(v[j].x);
           count(v[j].y);
@@ -488,8 +492,11 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], cons
 // level-0 scatter: (key, row id) pairs bucket-major; row id = index (or row_ids[index] when given)
 // THREADS x KPT rows per tile (JlShape); RIDS: row ids come as a column (the received pairs of the multi-GPU join) —
 // a template parameter so that the other callers do not carry the prefetched row-id registers
+#ifndef DBHIP_JL_SC0_WPE
+#define DBHIP_JL_SC0_WPE 6
+#endif
 template <bool RANK, bool RIDS, int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? DBHIP_JL_SC0_WPE : 1))) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ row_ids,
                                                                  unsigned long long first_row, size_t n,
                                                                  unsigned parts, unsigned k2_shift, unsigned k1,
@@ -1676,7 +1683,7 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
 // grid of the level-0 scatter: a multiple of 8 (one slice of workgroups per XCD)
 inline unsigned jl_scatter0_grid(size_t tiles, size_t cap) {
   static const int forced = [] { const char *e = getenv("DBHIP_JL_SC0_WGS"); return e ? atoi(e) : 0; }();  // experiment knob: workgroups per CU
-  if (forced >= 1 && forced <= 32) cap = cap / 8 * static_cast<size_t>(forced);
+  if (forced >= 1 && forced <= 32) cap = static_cast<size_t>(forced) * 256;  // (knob: per CU of a 256-CU chip)
   size_t g = tiles < cap ? tiles : cap;
   g = (g + 7) / 8 * 8;
   return static_cast<unsigned>(g ? g : 8);
@@ -1734,17 +1741,15 @@ hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const 
     if (e != hipSuccess) return e;
   }
   const size_t tiles = (n + kTile - 1) / kTile;
-  // persistent grid: the shape of 4096-row tiles keeps its eight workgroups per CU (measured equal from two to eight), the
-  // larger ones as many as are resident
-  size_t per_cu = 8;
-  if (kTile > 4096) {
-    int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
-      (void)hipGetLastError();
-      blocks = 1;
-    }
-    per_cu = static_cast<size_t>(blocks);
+  // persistent grid of the workgroups that are resident (round 4: the 4096-row shape ran with eight per CU where its
+  // registers allowed two; held to 80 VGPRs — amdgpu_waves_per_eu(6) — three are, and a grid of exactly those measured
+  // 1.5-2 % of the radix join at 2^26 rows: 1759-1777 -> 1726-1740 us on the same box)
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
+    (void)hipGetLastError();
+    blocks = 1;
   }
+  const size_t per_cu = static_cast<size_t>(blocks);
   hipLaunchKernelGGL(kernel, dim3(jl_scatter0_grid(tiles, static_cast<size_t>(dev.cus) * per_cu)), dim3(THREADS), lds, s, keys,
                      row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids);
   return hipSuccess;
