@@ -213,6 +213,9 @@ __global__ __launch_bounds__(kJlFusedThreads) void jl_hist_fused16_kernel(const 
   if (lo < hi && (reinterpret_cast<uintptr_t>(keys + lo) & 15u) == 0) {
     const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys + lo);
     const size_t n4 = (hi - lo) / 4;
+    // (round 4, measured and dropped: the next step's loads in flight while this step's keys are counted, two register
+    //  sets as in the group-by — 80.7 -> 99.6 us for the 256 MiB of keys of a 2^26-row side; eight loads per lane in
+    //  flight instead of four: partition of one side 572 -> 590 us, two: the same as four)
     for (size_t i = static_cast<size_t>(w) * kJlHistLoads * kJlFusedThreads + threadIdx.x; i < n4;
          i += static_cast<size_t>(kJlFusedWgPerGroup) * kJlHistLoads * kJlFusedThreads) {
       u32x4 v[kJlHistLoads];
@@ -620,36 +623,93 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const u32x2 *__res
     if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
 }
 
+// Level-1 scatter: a PERSISTENT grid of the resident workgroups over the "virtual tiles" (every level-0 bucket cut into
+// tiles of THREADS x KPT rows; tile_starts[b] = index of bucket b's first tile).  XCD x walks the x-th eighth of the
+// virtual tiles, its workgroups interleaved (workgroup j: tiles j, j + per, ...), so the tiles in flight on an XCD
+// belong to one or two level-0 buckets, whose k2 write frontiers then meet in ONE L2; a workgroup finds its next tile
+// by stepping on from the current one (the bucket changes every few steps: one or two loads), requests its rows
+// before the current tile's LDS work and waits for them right before the current tile's stores (the vmcnt rule of
+// jl_scatter0_kernel).  Until round 4 this was one tile per workgroup, each starting with a binary search for its
+// tile (eight to ten dependent loads) and then its row loads: radix join 2^22 / 2^24 / 2^26 / 2^27 rows 212 / 514 / 1737 /
+// 3240 us -> 205 / 496 / 1671 / 3144 (4096-row tiles), 2^30 rows 31.3 -> 26.8 ms (8192-row tiles; 16384-row ones 28.2:
+// their 32 prefetched words per lane no longer fit the 128 VGPRs of a 1024-thread workgroup).
 template <int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) void jl_scatter1_kernel(const u32x2 *__restrict__ rows,
-                                                                 const unsigned long long *__restrict__ starts0,
-                                                                 const unsigned long long *__restrict__ tile_starts,
-                                                                 unsigned parts, unsigned k1, unsigned k2,
-                                                                 unsigned long long *cursors1,
-                                                                 u32x2 *__restrict__ out_pairs, unsigned xcd_slices) {
+__global__ __launch_bounds__(THREADS) void jl_scatter1p_kernel(const u32x2 *__restrict__ rows,
+                                                               const unsigned long long *__restrict__ starts0,
+                                                               const unsigned long long *__restrict__ tile_starts,
+                                                               unsigned parts, unsigned k1, unsigned k2,
+                                                               unsigned long long *cursors1, u32x2 *__restrict__ out_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];
+  constexpr unsigned kTile = THREADS * KPT;
+  const unsigned long long total = tile_starts[k1];
+  const unsigned xcd = blockIdx.x % 8u, j = blockIdx.x / 8u, per = gridDim.x / 8u;  // host: gridDim.x % 8 == 0
+  const unsigned long long per_xcd = (total + 7) / 8;
+  const unsigned long long vend = (xcd + 1) * per_xcd < total ? (xcd + 1) * per_xcd : total;
+  unsigned long long vt = xcd * per_xcd + j;
+  if (vt >= vend) return;
   unsigned bucket;
   unsigned long long tile;
-  // xcd_slices: workgroups are dealt to the 8 XCDs round-robin by blockIdx; XCD x then takes the x-th contiguous eighth of
-  // the virtual tiles, i.e. a level-0 bucket's tiles — which all append to the same k2 write frontiers — meet in ONE L2
-  // (host: gridDim.x % 8 == 0)
-  const unsigned long long vt = xcd_slices ? static_cast<unsigned long long>(blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u
-                                           : blockIdx.x;
   if (!jl_locate(tile_starts, k1, vt, &bucket, &tile)) return;
-  const size_t lo = starts0[bucket] + tile * (THREADS * KPT);
-  const size_t hi = starts0[bucket + 1];
-  unsigned key[KPT], rid[KPT], dest[KPT];
+  auto load_tile = [&](unsigned b, unsigned long long t, unsigned (&k)[KPT], unsigned (&r)[KPT]) {
+    const size_t lo = starts0[b] + t * kTile, hi = starts0[b + 1];
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const size_t idx = lo + static_cast<size_t>(j) * THREADS + threadIdx.x;
-    const bool valid = idx < hi && idx < lo + (THREADS * KPT);
-    const u32x2 row = valid ? rows[idx] : u32x2{0u, 0u};
-    key[j] = row.x;
-    rid[j] = row.y;
-    dest[j] = valid ? jl_pid(key[j], parts) & (k2 - 1) : k2;
+    for (int q = 0; q < KPT; ++q) {
+      const size_t idx = lo + static_cast<size_t>(q) * THREADS + threadIdx.x;
+      const u32x2 row = idx < hi ? rows[idx] : u32x2{0u, 0u};  // (idx < lo + kTile by construction)
+      k[q] = row.x;
+      r[q] = row.y;
+    }
+  };
+  unsigned ckey[KPT], crid[KPT];
+  load_tile(bucket, tile, ckey, crid);
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    asm volatile("v_mov_b32 %0, %0" : "+v"(ckey[q]));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(crid[q]));
   }
-  jl_scatter_tile<1, THREADS, KPT>(key, rid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
-                     reinterpret_cast<unsigned *>(out_pairs), nullptr, s_mem);
+  while (true) {
+    // the next tile of this workgroup: step on from the current bucket
+    const unsigned long long nvt = vt + per;
+    const bool more = nvt < vend;
+    unsigned nbucket = bucket;
+    if (more)
+      while (nbucket + 1 < k1 && nvt >= tile_starts[nbucket + 1]) ++nbucket;
+    const unsigned long long ntile = more ? nvt - tile_starts[nbucket] : 0ull;
+    unsigned nkey[KPT], nrid[KPT], mkey[KPT], mrid[KPT];
+    if (more) {
+      load_tile(nbucket, ntile, nkey, nrid);
+    } else {
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) nkey[q] = nrid[q] = 0u;
+    }
+    auto wait_next = [&]() {
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mkey[q]) : "v"(nkey[q]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mrid[q]) : "v"(nrid[q]));
+      }
+    };
+    {
+      const size_t lo = starts0[bucket] + tile * kTile, hi = starts0[bucket + 1];
+      unsigned dest[KPT];
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) {
+        const size_t idx = lo + static_cast<size_t>(q) * THREADS + threadIdx.x;
+        dest[q] = idx < hi ? jl_pid(ckey[q], parts) & (k2 - 1) : k2;
+      }
+      jl_scatter_tile<1, THREADS, KPT, false>(ckey, crid, dest, k2, parts, k2 - 1, cursors1 + static_cast<size_t>(bucket) * k2,
+                                              reinterpret_cast<unsigned *>(out_pairs), nullptr, s_mem, wait_next);
+    }
+    if (!more) break;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      ckey[q] = mkey[q];
+      crid[q] = mrid[q];
+    }
+    vt = nvt;
+    bucket = nbucket;
+    tile = ntile;
+  }
 }
 
 // ---- per-partition build in LDS --------------------------------------------------------------------
@@ -1697,13 +1757,12 @@ inline unsigned jl_grid(size_t items, const DeviceInfo &dev, int per_cu) {
 
 
 // ---- tile shapes of the two scatter levels ---------------------------------------------------------------------------
-// 0: 512 threads x 8 rows = 4096-row tiles (36 KiB + 16 B per bucket of LDS: four workgroups per CU by LDS, two by their
-//    84 VGPRs) — the shape every size up to 2^27 rows was tuned on;
-// 1: 1024 x 8 = 8192 rows;  2: 1024 x 16 = 16384 rows (128 KiB of LDS: one workgroup per CU).
+// 0: 512 threads x 8 rows = 4096-row tiles (36 KiB + 16 B per bucket of LDS) — the shape every size up to 2^27 rows was
+//    tuned on;  1: 1024 x 8 = 8192 rows;  2 (level 0 only): 1024 x 16 = 16384 rows (128 KiB of LDS: one workgroup per CU).
 // A tile of T rows into nb buckets writes runs of T / nb rows and takes one returning global atomic per bucket: with the
 // 586 x 1024 buckets of a 2^30-row side a 4096-row tile writes 56- and 32-byte runs and one atomic per 7 / 4 rows (level 0
 // at 2.8 TB/s, level 1 at 2.6, against 4.0 / 3.9 at 2^26 rows with 293 x 128 buckets).  DBHIP_JL_T0 / DBHIP_JL_T1 force a
-// shape (experiments).
+// shape (experiments; T1 = 2 reads as 1).
 struct JlShape {
   int t0, t1;
 };
@@ -1716,15 +1775,16 @@ inline int jl_env_shape(const char *name) {
 inline JlShape jl_shape_for(size_t n, unsigned k1, unsigned k2) {
   static const int f0 = jl_env_shape("DBHIP_JL_T0"), f1 = jl_env_shape("DBHIP_JL_T1");
   (void)n;
-  // Measured (radix join, us, t0/t1; same box): 2^26 rows (293 x 128 buckets) 0/0 1838, 1/1 1862, 2/2 2039; 2^27 (293 x 256)
-  // 0/0 3406, 1/1 3502, 2/2 3805; 2^28 (586 x 256) 0/0 7776, 1/0 7521, 2/0 7261, 2/1 7425, 2/2 8089; 2^29 (586 x 512) 0/0
-  // 16214, 2/0 15225, 1/1 15196, 2/1 14567, 2/2 15836; 2^30 (586 x 1024) 0/0 35256, 2/0 33994, 0/2 33265, 1/2 32852, 2/2 32558.
+  // Measured (radix join, us, t0/t1; same box per size).  Level 1 one tile per workgroup, before it became persistent:
+  // 2^26 rows (293 x 128 buckets) 0/0 1838, 1/1 1862, 2/2 2039; 2^27 (293 x 256) 0/0 3406, 1/1 3502, 2/2 3805; 2^28 (586 x 256)
+  // 0/0 7776, 1/0 7521, 2/0 7261, 2/1 7425, 2/2 8089; 2^29 (586 x 512) 0/0 16214, 2/0 15225, 1/1 15196, 2/1 14567, 2/2 15836;
+  // 2^30 (586 x 1024) 0/0 35256, 2/0 33994, 0/2 33265, 1/2 32852, 2/2 32558.  Persistent level 1: 2^26 x/0 1671, x/1 1703;
+  // 2^27 x/0 3144, x/1 3157; 2^28 2/0 6829, 2/1 6769, 0/1 7181, 1/1 7007; 2^30 2/0 29565, 2/1 26830, 1/1 27381, 0/1 27871.
   JlShape sh{0, 0};
   if (k1 >= 512) sh.t0 = 2;
-  if (k2 >= 1024) sh.t1 = 2;
-  else if (k2 >= 512) sh.t1 = 1;
+  if (k2 >= 512) sh.t1 = 1;
   if (f0 >= 0) sh.t0 = f0;
-  if (f1 >= 0) sh.t1 = f1;
+  if (f1 >= 0) sh.t1 = f1 > 1 ? 1 : f1;
   return sh;
 }
 
@@ -1771,28 +1831,33 @@ hipError_t jl_launch_scatter0(int shape, const DeviceInfo &dev, hipStream_t s, c
 template <int THREADS, int KPT>
 hipError_t jl_launch_scatter1_shape(hipStream_t s, size_t n, const u32x2 *rows, const unsigned long long *starts0,
                                     const unsigned long long *tstarts0, unsigned parts, unsigned k1, unsigned k2,
-                                    unsigned long long *cursors1, u32x2 *out) {
+                                    unsigned long long *cursors1, u32x2 *out, const DeviceInfo &dev) {
   constexpr unsigned kTile = THREADS * KPT;
   const size_t lds = jl_scatter_lds_bytes(k2, kTile, THREADS);
-  auto kernel = jl_scatter1_kernel<THREADS, KPT>;
+  auto kernel = jl_scatter1p_kernel<THREADS, KPT>;
   if (lds > 48 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  static const bool xcd = [] { const char *e = getenv("DBHIP_JL_SC1_XCD"); return !(e && e[0] == '0'); }();  // A/B knob
-  size_t vtiles = (n + kTile - 1) / kTile + k1;  // every bucket's last tile may be ragged
-  vtiles = (vtiles + 7) / 8 * 8;
-  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(vtiles)), dim3(THREADS), lds, s, rows, starts0, tstarts0, parts, k1, k2,
-                     cursors1, out, xcd ? 1u : 0u);
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
+    (void)hipGetLastError();
+    blocks = 1;
+  }
+  const size_t vtiles = ((n + kTile - 1) / kTile + k1 + 7) / 8 * 8;  // every bucket's last tile may be ragged
+  size_t grid = static_cast<size_t>(dev.cus) * blocks / 8 * 8;       // the resident workgroups, a whole number per XCD
+  if (grid < 8) grid = 8;
+  if (grid > vtiles) grid = vtiles;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(THREADS), lds, s, rows, starts0, tstarts0, parts, k1, k2,
+                     cursors1, out);
   return hipSuccess;
 }
 inline hipError_t jl_launch_scatter1(int shape, hipStream_t s, size_t n, const u32x2 *rows, const unsigned long long *starts0,
                                      const unsigned long long *tstarts0, unsigned parts, unsigned k1, unsigned k2,
-                                     unsigned long long *cursors1, u32x2 *out) {
-  return shape == 0   ? jl_launch_scatter1_shape<512, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out)
-         : shape == 1 ? jl_launch_scatter1_shape<1024, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out)
-                      : jl_launch_scatter1_shape<1024, 16>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out);
+                                     unsigned long long *cursors1, u32x2 *out, const DeviceInfo &dev) {
+  return shape == 0 ? jl_launch_scatter1_shape<512, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out, dev)
+                    : jl_launch_scatter1_shape<1024, 8>(s, n, rows, starts0, tstarts0, parts, k1, k2, cursors1, out, dev);
 }
 
 }  // namespace
@@ -1886,7 +1951,7 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
     //  precomputed {bucket, tile} map in place of the workgroup's binary search over tile_starts — eight dependent
     //  loads in front of its row loads — measured the same as well (partition of 2^26 rows 610 vs 615 us), and so did
     //  the tile shapes 512x16 / 512x4 / 1024x4 once more (723 / 661 / 699 us against 610).)
-    const hipError_t e1 = jl_launch_scatter1(shape.t1, s, n, rows_a, starts0, tstarts0, parts, k1, k2, cursors1, rows_b);
+    const hipError_t e1 = jl_launch_scatter1(shape.t1, s, n, rows_a, starts0, tstarts0, parts, k1, k2, cursors1, rows_b, dev);
     if (e1 != hipSuccess) return static_cast<int>(e1);
     *out_pairs = reinterpret_cast<const unsigned *>(rows_b);
     *out_starts = starts1;
