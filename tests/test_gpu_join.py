@@ -195,6 +195,33 @@ def test_join_build_with_giant_partitions(kind, n):
     _check_grouped_join(build, probe)
 
 
+def test_many_giant_partitions_of_many_slices_each_count_exactly():
+    """Sixty hot keys of 40000..90000 rows each in a 2^22-row build: dozens of giant partitions, five to eleven 8192-row
+    slices each, whose per-key counts are added slice by slice with relaxed memory-side atomics and turned into positions
+    by whichever workgroup finishes a giant's last slice (jl_giant_count).  Every hot key's count and id range is checked
+    exactly, so a lost or doubled slice shows as a wrong count, not as a rare mis-join."""
+    rng = np.random.default_rng(41)
+    n = 1 << 22
+    build = po.gen_uniform_u32(n, 42, 0, n - 1)
+    hot = rng.choice(np.arange(1, 1 << 30, dtype=np.uint32), 60, replace=False)
+    sizes = rng.integers(40000, 90000, hot.size)
+    at = 0
+    for k, c in zip(hot, sizes):
+        build[at: at + c] = k
+        at += c
+    build = rng.permutation(build)
+    probe = np.concatenate([hot, po.gen_uniform_u32(1 << 16, 43, 0, n - 1)]).astype(np.uint32)
+    _check_grouped_join(build, probe)
+    # and through the radix join (the giants' scratch sub-tables)
+    from dwarf_bench_amd import ops
+    rid, pos, cnt, ids = (t.cpu().numpy().view(np.uint32) for t in ops.radix_join(_dev(build), _dev(probe)))
+    assert np.array_equal(cnt, po.join_counts_fast(build, probe).astype(np.uint32)[rid])
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    in_order = build[ids]
+    hit = cnt > 0
+    assert np.array_equal(in_order[pos[hit]], probe[rid[hit]]) and np.array_equal(in_order[pos[hit] + cnt[hit] - 1], probe[rid[hit]])
+
+
 def _keys_of_partition_of(parts, partition, how_many):
     cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
     mine = cand[(_fmix32(cand) * parts) >> 32 == partition][:how_many]

@@ -109,10 +109,23 @@ def test_crowded_keys_cost_no_multiple_of_spread_keys():
         assert ops.workspace_status(plan.ws) == 0
         return sorted(out[1:])[2]
 
-    spread = median_us(rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32))
+    # a timing ratio inside a functional suite: one noisy median on a shared box must not fail the run — the bound has to
+    # be missed three times in a row (the correctness of these inputs is test_sort_keys_that_crowd_into_few_digits'
+    # business); DBENCH_SKIP_PERF_TESTS=1 skips it altogether
+    import os
+    if os.environ.get("DBENCH_SKIP_PERF_TESTS"):
+        pytest.skip("DBENCH_SKIP_PERF_TESTS is set")
+    spread_keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
     for kind in ("two values", "90 % one value"):
-        crowded = median_us(_crowded(kind, n, rng))
-        assert crowded < 2.2 * spread, (kind, crowded, spread)
+        crowded_keys = _crowded(kind, n, rng)
+        seen = []
+        for _attempt in range(3):
+            spread, crowded = median_us(spread_keys), median_us(crowded_keys)
+            seen.append((crowded, spread))
+            if crowded < 2.2 * spread:
+                break
+        else:
+            raise AssertionError((kind, seen))
 
 
 @pytest.mark.parametrize("bits", [8, 4])
