@@ -99,7 +99,15 @@ def _traffic_source():
         src = json.loads(p.read_text()).get("_source")
     except Exception:
         src = None
-    return {"file": "profiles/hbm_traffic.json", "measured_in_this_run": False, "provenance": src}
+    # the counters belong to ONE state of the device code: its content hash is in the file, this run's is computed here
+    try:
+        from dwarf_bench_amd.build import kernel_tree_sha256
+        now = kernel_tree_sha256()
+    except Exception:
+        now = None
+    then = (src or {}).get("kernel_tree_sha256")
+    return {"file": "profiles/hbm_traffic.json", "measured_in_this_run": False, "provenance": src,
+            "kernel_tree_sha256_now": now, "collected_on_this_kernel_tree": bool(now and then and now == then)}
 
 
 def _peak_source():

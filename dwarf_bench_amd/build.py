@@ -45,6 +45,21 @@ def _run(cmd: list[str], cwd: Path | None = None) -> None:
     subprocess.run([str(c) for c in cmd], check=True, cwd=cwd)
 
 
+def kernel_tree_sha256() -> str:
+    """Content hash of the device code: every file under csrc/ plus include/dbhip.h, by name and bytes.  The profiler
+    passes that bench.py's `roofline.traffic` comes from record it (tools/profile_summary.py -> profiles/hbm_traffic.json),
+    bench.py reports whether it still matches, and tests/test_bench_contract.py fails when a kernel changed after the
+    counters were collected.  (A content hash rather than `git log -1 -- csrc`: the GPU box has no .git.)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "dbhip.h"]:
+        h.update(f.name.encode())
+        h.update(b"\0")
+        h.update(f.read_bytes())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def build_hip(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950: every .hip under csrc/ into one shared library."""
     LIB.mkdir(exist_ok=True)

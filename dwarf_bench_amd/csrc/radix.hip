@@ -660,17 +660,20 @@ __device__ __forceinline__ unsigned rs_scatter_tile(const unsigned *__restrict__
       const unsigned kk = s_keys[p];
       const unsigned kx = kk ^ xor_mask;
       // the tile as it now lies in LDS must be sorted by its low (shift + BITS) bits (stable ranking, here and in every
-      // earlier pass): my left neighbour's may not exceed mine.  The neighbour's key comes over DPP (wave_shr:1); lane 0
-      // of a wave reads its neighbour — the last key of the wave before — from LDS (round 4: until then the pairs across
-      // wave boundaries, one in 64, went unchecked), so EVERY adjacent pair of the tile is compared.
+      // earlier pass): my left neighbour's may not exceed mine.  The neighbour's key comes over DPP (wave_shr:1; lane 0
+      // keeps the 0: the pairs across the 64-key rows, one in 64, go unchecked).
       const unsigned mine = kx & low_mask;
-      unsigned left = __builtin_amdgcn_update_dpp(0u, mine, 0x138, 0xf, 0xf, false);
-      if ((tid & (kWave - 1)) == 0 && p > 0) left = (s_keys[p - 1] ^ xor_mask) & low_mask;
+      const unsigned left = __builtin_amdgcn_update_dpp(0u, mine, 0x138, 0xf, 0xf, false);
       bad |= left > mine ? 1u : 0u;
       const unsigned d = (kx >> shift) & (kRadix - 1);
       dst[s_goff[d] + p] = kk;
     }
   }
+  // (Round 4 measured what comparing the pairs the DPP compare cannot see — last key of a 64-key row against the first of
+  //  the next, one in 64 — would cost: as a read by lane 0 inside the loop above 10 % of the sort (200 -> 221 us for 2^24
+  //  keys: a divergent LDS read in front of every row's stores), as one thread per row boundary behind the loop 1.2-1.5 %
+  //  (201.4 -> 203.9 us, 4-bit 369 -> 375).  Not taken: this is a tripwire for an unstable rank, which shows inside the
+  //  rows of a wave as surely as between them; include/dbhip.h says what it covers.)
   __syncthreads();
   return bad;
 }
@@ -748,7 +751,8 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_chunk_scatter_ker
 // on a workgroup-uniform vote; the result is written back to `keys`.
 template <int BITS, bool ARANK>
 __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kernel(unsigned *keys, unsigned n,
-                                                                                  unsigned xor_mask, unsigned *status) {
+                                                                                  unsigned xor_mask, unsigned *status,
+                                                                                  unsigned inject) {
   constexpr int kRadix = 1 << BITS;
   constexpr int kPasses = 32 / BITS;
   __shared__ unsigned s_cnt[kRsWaves][kRadix];
@@ -814,6 +818,19 @@ __global__ __launch_bounds__(kRsThreads, DBHIP_RS_WPE) void rs_single_tile_kerne
       }
     }
     __syncthreads();
+    if (inject) {  // test hook (uniform), as in rs_scatter_tile: swap the first neighbours that share the digit and differ below it
+      if (tid == 0)
+        for (unsigned p = 0; p + 1 < n; ++p) {
+          const unsigned a = s_keys[p] ^ xor_mask, b = s_keys[p + 1] ^ xor_mask;
+          if ((((a ^ b) >> shift) & (kRadix - 1)) == 0 && ((a ^ b) & low_mask) != 0) {
+            const unsigned t = s_keys[p];
+            s_keys[p] = s_keys[p + 1];
+            s_keys[p + 1] = t;
+            break;
+          }
+        }
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < kRsKpt; ++j) {
       const unsigned idx = wave_first + j * kWave;
@@ -863,10 +880,10 @@ int radix_sort_impl(unsigned *keys, unsigned *tmp, size_t n, unsigned xor_mask, 
     if (e0 != hipSuccess) return static_cast<int>(e0);
     if (arank)
       hipLaunchKernelGGL((rs_single_tile_kernel<BITS, true>), dim3(1), dim3(kRsThreads), 0, s, keys,
-                         static_cast<unsigned>(n), xor_mask, &hdr->status);
+                         static_cast<unsigned>(n), xor_mask, &hdr->status, rank_fault_injection());
     else
       hipLaunchKernelGGL((rs_single_tile_kernel<BITS, false>), dim3(1), dim3(kRsThreads), 0, s, keys,
-                         static_cast<unsigned>(n), xor_mask, &hdr->status);
+                         static_cast<unsigned>(n), xor_mask, &hdr->status, rank_fault_injection());
     return launch_status();
   }
   hipError_t e = fill_async(workspace, 0, kRsCountsOff, s);  // header + totals (+ bases)

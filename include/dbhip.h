@@ -125,10 +125,11 @@ int dbhip_radix_sort_i32(int32_t *keys, int32_t *tmp, size_t n, int radix_bits, 
 /* How the scatter ranks keys on the current device: 1 = one returning LDS atomic per key, 0 = wave ballots, -1 = no
  * device.  The atomic ranking is stable only if same-address lanes of one ds_add_rtn are served in lane order; gfx950
  * does that, the ISA manual does not promise it.  It is therefore (a) the default on gfx950 only, (b) watched by every
- * tile of every sort through the invariant it exists for: every adjacent pair of keys of a tile re-ordered by the pass's
- * digit is compared under the mask of the digits sorted so far (DBHIP_DEV_RANK_ORDER in the status word if a pair is out
- * of order: about 2 % of the sort's time; pairs that straddle two tiles are not compared — a tripwire for an unstable
- * rank or a damaged earlier pass, not a proof of sortedness), and (c) pinned by dbhip_radix_sort_prepare.  The
+ * tile of every sort through the invariant it exists for: inside each run of 64 keys (a wave's row) of a tile re-ordered
+ * by the pass's digit, every key is compared with its left neighbour under the mask of the digits sorted so far
+ * (DBHIP_DEV_RANK_ORDER in the status word if a pair is out of order: about 2 % of the sort's time).  The pairs that
+ * straddle two rows (one in 64) or two tiles are NOT compared: a tripwire for an unstable rank or a damaged earlier
+ * pass, not a proof of sortedness.  And (c) pinned by dbhip_radix_sort_prepare.  The
  * same ranking is used inside and outside graph captures.  DBHIP_RS_RANK=ballot|atomic overrides.                 */
 int dbhip_radix_sort_rank_mode(void);
 /* OPTIONAL calibration, the one call of this library that allocates (a scratch word) and SYNCHRONISES `stream`: runs

@@ -6,7 +6,7 @@
 # Raw output goes to gpurun_out/prof_<tag>/; tools/profile_summary.py condenses it into profiles/.
 #   tools/profile_round.sh <tag> <git head the numbers belong to>
 set -euo pipefail
-tag="${1:-r03}"; head="${2:-unknown}"
+tag="${1:-r04}"; head="${2:-unknown}"
 repo="$(pwd)"
 out="$repo/gpurun_out/prof_$tag"
 mkdir -p "$out"

@@ -23,6 +23,8 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from dwarf_bench_amd.build import kernel_tree_sha256  # noqa: E402  (the device code the counters were collected on)
 
 # dwarf -> (regex of its kernels, regex of the anchor kernel launched exactly once per call, double FETCH_SIZE?)
 DWARFS = {
@@ -31,7 +33,7 @@ DWARFS = {
     "sort_4bit": (r"rs_\w+<4", r"rs_histogram", True),
     "groupby": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", True),
     # join: 4-B/lane reads and random 16-B gathers — widths the guide calls uncalibrated: raw counter, not doubled
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_build_kernel<false>", False),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false|jl_giant_(count|ids)_kernel", r"jl_build_kernel<false", False),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", False),
 }
 
@@ -62,13 +64,13 @@ CONFIGS = {
     "sort_2p24_4bit": (r"rs_\w+<4|rs_finalize", r"rs_histogram_kernel<4", r"rs_finalize_kernel"),
     "groupby_2p26_2p16": (r"gb_aggregate\w*kernel|gb_reduce\w*kernel", r"gb_aggregate\w*kernel", r"gb_reduce\w*kernel"),
     # (the two launches for giant partitions close a build; they find none on the bench's uniform keys)
-    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false>|jl_giant_(count|ids)_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
+    "join_build": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<false|jl_giant_(count|ids)_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
     "join_probe": (r"jl_probe_kernel", r"jl_probe_kernel", r"jl_probe_kernel"),
     # the radix join: both sides through the partitioner, then the fused build + probe launch (+ two for giants)
-    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true>|jl_giant_\w+_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
+    "join_radix_2p26": (r"jl_(hist|offsets|scatter)\w*|jl_build_kernel<true|jl_giant_\w+_kernel", r"jl_hist0_kernel|jl_hist_fused\w*_kernel", r"jl_giant_ids_kernel"),
 }
 # a kernel of ANOTHER configuration that shares kernels with this one: a call that meets it is not this configuration's
-FOREIGN = {"join_build": r"jl_build_kernel<true>", "join_radix_2p26": r"jl_build_kernel<false>|jl_probe_kernel"}
+FOREIGN = {"join_build": r"jl_build_kernel<true", "join_radix_2p26": r"jl_build_kernel<false|jl_probe_kernel"}
 
 
 def read_trace(raw: Path):
@@ -156,7 +158,7 @@ def main():
         "_comment": "rocprofv3 --kernel-trace of `python3 bench.py --steps 20 --warmup 3 --no-cpu --no-sweep` split per "
                     "BASELINE configuration (tools/profile_summary.py); durations in us; span = first kernel start -> "
                     "last kernel end of one call; fractions against 8.0 TB/s",
-        "git_head": git_head, "configurations": headline(raw)}, indent=1))
+        "git_head": git_head, "kernel_tree_sha256": kernel_tree_sha256(), "configurations": headline(raw)}, indent=1))
     per_kernel = {}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("dbhip::"):
@@ -170,6 +172,7 @@ def main():
                    "--pmc WRITE_SIZE (separate passes, tools/profile_round.sh)", "git_head": git_head, "kernels": per_kernel}, indent=1))
 
     traffic = {"_source": {"tool": "tools/profile_round.sh -> tools/profile_summary.py", "round_tag": tag, "git_head": git_head,
+                           "kernel_tree_sha256": kernel_tree_sha256(),
                            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 10 --warmup 2 "
                                       "--no-cpu --no-pjoin --no-sweep (one counter per pass)"},
                "_comment": "HBM bytes per call from rocprofv3 --pmc passes (profiles/%s_pmc.json); counters are KiB; "
