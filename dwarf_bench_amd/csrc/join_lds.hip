@@ -499,7 +499,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], cons
 #define DBHIP_JL_SC0_WPE 6
 #endif
 template <bool RANK, bool RIDS, int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? DBHIP_JL_SC0_WPE : 1))) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 && !RIDS ? DBHIP_JL_SC0_WPE : 1))) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ row_ids,
                                                                  unsigned long long first_row, size_t n,
                                                                  unsigned parts, unsigned k2_shift, unsigned k1,
@@ -954,7 +954,7 @@ __device__ __forceinline__ void jl_spill_list(const JlSpill &sp, unsigned part, 
 // kInline: the workgroup that finds its partition overfull builds the spill table itself, at once (small inputs: no
 // launch behind this one looks at the list); otherwise it lists the partition for the tail of jl_giant_ids_kernel.
 template <bool kMatch, bool kInline>
-__global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu(6))) void jl_build_kernel(const unsigned *__restrict__ pkeys,
+__global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu(kInline ? 4 : 6))) void jl_build_kernel(const unsigned *__restrict__ pkeys,
                                                                    const unsigned *__restrict__ prids,
                                                                    const unsigned long long *__restrict__ starts,
                                                                    u32x2 *__restrict__ table, unsigned parts,
