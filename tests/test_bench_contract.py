@@ -1,5 +1,5 @@
-"""The bench line's schema (the driver's contract + roofline + cpu_baseline), checked on the committed N=1 line of
-this round (profiles/r02_bench_n1.json) and on bench.py's argument defaults.  No GPU needed."""
+"""The bench line's schema (the driver's contract + roofline + cpu_baseline), checked on the newest committed N=1 line
+(profiles/r*_bench_n1.json) and on bench.py's argument defaults.  No GPU needed."""
 import json
 import subprocess
 import sys
@@ -8,8 +8,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
+def _newest(pattern):
+    files = sorted((ROOT / "profiles").glob(pattern))
+    assert files, pattern
+    return files[-1]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
+    line = json.loads(_newest("r*_bench_n1.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -42,15 +48,15 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_headline_profile_recomputes_the_roofline_fractions():
-    """profiles/r02_headline.json (kernel trace split per BASELINE configuration): every fraction follows from the
+    """profiles/r*_headline.json (kernel trace split per BASELINE configuration): every fraction follows from the
     spans and algorithmic bytes in the file itself, and the scan's agrees with the bench line within 3 %"""
-    head = json.loads((ROOT / "profiles" / "r02_headline.json").read_text())["configurations"]
+    head = json.loads(_newest("r*_headline.json").read_text())["configurations"]
     for name in ("scan_2p28", "sort_2p24_8bit", "sort_2p24_4bit", "groupby_2p26_2p16", "join_build", "join_probe", "join_2p26"):
         assert name in head, name
     for name, c in head.items():
         if "frac_of_8TBps_from_span" in c:
             assert abs(c["frac_of_8TBps_from_span"] - c["algorithmic_bytes"] / (c["span_us_avg"] * 1e-6) / 8e12) < 1e-9
-    line = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
+    line = json.loads(_newest("r*_bench_n1.json").read_text())
     assert abs(head["scan_2p28"]["frac_of_8TBps_from_span"] / line["roofline"]["frac"] - 1) < 0.03
     k = head["scan_2p28"]["kernels"]
     assert any("scan_chunk_kernel" in n for n in k) and any("scan_move_kernel" in n for n in k)
@@ -98,3 +104,19 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     assert r.returncode != 0
     assert "started ranks 0..1 as child processes" in r.stderr and r.stderr.count("needs a GPU") == 2
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_traffic_figures_belong_to_this_device_code():
+    """`roofline.traffic` and every `pmc_traffic_bytes` of the bench line come from committed profiler passes
+    (profiles/hbm_traffic.json): they are only worth reporting for the kernels they were collected on.  The file and the
+    newest headline profile carry the content hash of csrc/ + include/dbhip.h at collection time; a kernel edited after that
+    fails here until tools/profile_round.sh has run again."""
+    sys.path.insert(0, str(ROOT))
+    from dwarf_bench_amd.build import kernel_tree_sha256
+    now = kernel_tree_sha256()
+    traffic = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+    assert traffic["_source"]["kernel_tree_sha256"] == now, "device code changed since the PMC passes: run tools/profile_round.sh"
+    assert json.loads(_newest("r*_headline.json").read_text())["kernel_tree_sha256"] == now
+    line = json.loads(_newest("r*_bench_n1.json").read_text())
+    src = line["roofline"]["traffic_source"]
+    assert src["collected_on_this_kernel_tree"] is True and src["kernel_tree_sha256_now"] == now

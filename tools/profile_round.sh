@@ -19,6 +19,8 @@ echo "[profile] FETCH_SIZE done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$repo/bench.py" --steps 10 --warmup 2 --no-cpu --no-pjoin --no-sweep > "$out/bench_under_pmc_write.log" 2>&1
 echo "[profile] WRITE_SIZE done"
 cd "$repo"
+# the device code these counters belong to (content hash; tools/profile_summary.py refuses a summary on another tree)
+python3 -c "import sys; sys.path.insert(0, '.'); from dwarf_bench_amd.build import kernel_tree_sha256; print(kernel_tree_sha256())" > "$out/kernel_tree_sha256.txt"
 python3 tools/profile_summary.py "$out" "$tag" "$head"
 # the self-measured peaks bench.py divides by (RANDOM_GATHER_PEAK_G, LDS_ATOMIC_PEAK_G, the nt-read rate): raw output of
 # the two micro-benchmarks, with the command and the git head, kept as profiles/<tag>_ubench.txt

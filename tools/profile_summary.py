@@ -147,6 +147,10 @@ def main():
     git_head = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     prof = ROOT / "profiles"
     prof.mkdir(exist_ok=True)
+    stamp = raw / "kernel_tree_sha256.txt"  # written on the GPU box at collection time (tools/profile_round.sh)
+    if stamp.exists() and stamp.read_text().strip() != kernel_tree_sha256():
+        sys.exit(f"{raw}: collected on device code {stamp.read_text().strip()[:12]}, this tree is {kernel_tree_sha256()[:12]} — "
+                 "profiles/ left untouched")
     stats = sorted((raw / "kt").rglob("*kernel_stats.csv"))
     fetch = read_pmc(raw / "pmc_fetch", "FETCH_SIZE")
     write = read_pmc(raw / "pmc_write", "WRITE_SIZE")
