@@ -378,7 +378,7 @@ def bench_pjoin(steps, warmup, log2_total=30, dist=None, group=None):
             "workload": f"radix-partitioned HashJoin 2^{log2_total} x 2^{log2_total} uint32 keys over {world} GPU(s)"}
 
 
-def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo=False):
+def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo=False, sub_joins=None):
     """The same join on the C++ host the `PartitionedJoinHip` dwarf runs on (dwarf_bench_amd/host/pjoin_engine.cpp
     through libdbench.so): one process per GPU, per-rank compute + exchange streams, counts by ncclAllGather, one
     RCCL send/recv group per relation.  solo: this process alone joins the whole input on its GPU (plain local join —
@@ -392,6 +392,13 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
         box = [pjoin_native.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         nid = box[0]
+    # sub_joins: the engine cuts every rank's rows into that many independent joins whose exchanges follow each other on
+    # the links while the one before is joined locally (host/pjoin_engine.hpp Options::sub_joins; default 2); the knob
+    # travels through the environment, read when the engine is created — the same on every rank
+    if sub_joins is not None:
+        os.environ["DWARF_BENCH_PJOIN_SUBJOINS"] = str(sub_joins)
+    else:
+        os.environ.pop("DWARF_BENCH_PJOIN_SUBJOINS", None)
     eng = pjoin_native.NativePartitionedJoin(total, rank if multi else 0, world if multi else 1, local, nid,
                                              direct_single=not multi)
 
@@ -444,7 +451,8 @@ def bench_pjoin_native(steps, warmup, log2_total, dist, rank, world, local, solo
             us = last.get(f"exchange_{rel}_us") or 0.0
             exchange[f"exchange_{rel}_us"] = round(us, 1)
             exchange[f"achieved_gbs_per_link_{rel}"] = (link_bytes / us / 1e3) if us > 0 else None
-    return {"rows": 2 * total, "rccl_ranks_seen": int(seen.item()), "rank_devices": devices, "exchange_links": exchange, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
+    return {"rows": 2 * total, "sub_joins": 1 if not multi else (sub_joins or 2), "rccl_ranks_seen": int(seen.item()),
+            "rank_devices": devices, "exchange_links": exchange, "ms_per_step": ms, "mrows_per_s": 2 * total / (ms * 1e3), "matches": w[3],
             "rows_exchanged": w[4], "bytes_sent_per_gpu": w[4] * 8 / n_ranks,
             "max_over_mean_rows_per_rank": float(mx[5]) * n_ranks / max(w[5], 1),
             "checks": {"damaged_pairs": w[0], "misrouted_keys": w[1], "wrong_probe_rows": w[2],
@@ -651,6 +659,18 @@ def pjoin_section(args, dist, rank, world, local, barrier, out):
                 section.update({"single_gpu_ms_per_step": c1["ms_per_step"], "single_gpu_mrows_per_s": c1["mrows_per_s"],
                                 "speedup_vs_1gpu": c1["ms_per_step"] / cx["ms_per_step"],
                                 "matches_equal_single_gpu": cx["matches"] == c1["matches"]})
+            # the same join with one and with four sub-joins per step (the figures above are the default, two): how much
+            # of the exchange the pipeline hides on THIS node — one join per step is the schedule of rounds 1-3
+            dog.leg = "C++ engine, all ranks, sub-join sweep"
+            sweep = {}
+            for sj in (1, 4):
+                sx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local, sub_joins=sj)
+                torch.cuda.empty_cache()
+                sweep[str(sj)] = {"ms_per_step": sx["ms_per_step"], "matches": sx["matches"],
+                                  "exchange_links": sx["exchange_links"], "checks": sx["checks"]}
+            if rank == 0:
+                sweep["2"] = {"ms_per_step": cx["ms_per_step"], "matches": cx["matches"]}
+                section["sub_joins_sweep"] = sweep
         except Exception as e:
             if rank == 0:
                 section["error"] = repr(e)

@@ -940,7 +940,7 @@ void PartitionedJoinHip::_run(const size_t n, Meter &meter) {
   std::cout << "PartitionedJoinHip: " << P << " rank(s) on " << std::min<int>(P, ndev) << " GPU(s), exchange by "
             << (engine.uses_rccl() ? "RCCL send/recv group"
                                    : (po.direct_single && P == 1 ? "nothing (direct local join)" : "hipMemcpyPeerAsync"))
-            << "\n";
+            << (engine.sub_joins() > 1 ? ", " + std::to_string(engine.sub_joins()) + " pipelined sub-joins" : std::string()) << "\n";
   engine.plan();
 
   // host copy of the global columns for the host-side check

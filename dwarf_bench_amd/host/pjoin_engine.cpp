@@ -48,6 +48,8 @@ uint64_t piece_elems() {
   return v;
 }
 
+constexpr unsigned kMaxSub = 4;  // sub-joins per step (Options::sub_joins)
+
 struct DevMem {  // hipMalloc on a given device; grows, never shrinks
   int dev = 0;
   void *p = nullptr;
@@ -81,20 +83,23 @@ struct Rank {
   int device = 0;
   hipStream_t compute = nullptr, xchg = nullptr;
   hipEvent_t ev_start = nullptr, ev_part_r = nullptr, ev_part_s = nullptr, ev_cnt_r = nullptr, ev_cnt_s = nullptr,
-             ev_x0 = nullptr, ev_xr = nullptr, ev_xs = nullptr, ev_build0 = nullptr, ev_build = nullptr,
-             ev_probe0 = nullptr, ev_done = nullptr;
+             ev_build = nullptr, ev_done = nullptr;
+  // per sub-join h and relation: the send/recv group's begin and end on the exchange stream, the local work's on the compute stream
+  hipEvent_t ev_x0[2][kMaxSub] = {}, ev_x1[2][kMaxSub] = {}, ev_l0[2][kMaxSub] = {}, ev_l1[2][kMaxSub] = {};
   size_t lo = 0, n_local = 0;
   DevMem build, probe;              // input shards
   DevMem pk_r, pr_r, pk_s, pr_s;    // bucket-major (key, global row id) of both relations
-  DevMem cnt_dev;                   // [0,P) R send counts, [P,2P) S send counts
-  DevMem mat_dev;                   // gathered P x P matrices (R then S), row = sender
+  DevMem cnt_dev;                   // [0,HP) R send counts, [HP,2HP) S send counts; bucket b = destination rank * H + sub-join
+  DevMem mat_dev;                   // gathered P x HP matrices (R then S), row = sender
   uint64_t *mat_host = nullptr;     // pinned copy
   DevMem part_ws;
   size_t part_ws_bytes = 0;
   DevMem rk, rr, sk, sr;            // received pairs
   DevMem join_ws, ids, pos, cnt;
   DevMem out_rid;                   // radix local join: probe row ids in result order (results are not in received order)
-  size_t recv_r = 0, recv_s = 0;
+  size_t recv_r = 0, recv_s = 0;    // all sub-joins together
+  size_t sub_r[kMaxSub] = {}, sub_s[kMaxSub] = {};  // rows received per sub-join; its rows start at off_r / off_s
+  size_t off_r[kMaxSub + 1] = {}, off_s[kMaxSub + 1] = {};
   DevMem chk;                       // validator results / conservation sums
   ncclComm_t comm = nullptr;
 
@@ -109,9 +114,12 @@ struct Rank {
     if (compute) (void)hipStreamSynchronize(compute);
     if (xchg) (void)hipStreamSynchronize(xchg);
     if (comm) (void)ncclCommDestroy(comm);
-    for (hipEvent_t e : {ev_start, ev_part_r, ev_part_s, ev_cnt_r, ev_cnt_s, ev_x0, ev_xr, ev_xs, ev_build0, ev_build,
-                         ev_probe0, ev_done})
+    for (hipEvent_t e : {ev_start, ev_part_r, ev_part_s, ev_cnt_r, ev_cnt_s, ev_build, ev_done})
       if (e) (void)hipEventDestroy(e);
+    for (auto *arr : {&ev_x0, &ev_x1, &ev_l0, &ev_l1})
+      for (auto &rel : *arr)
+        for (hipEvent_t e : rel)
+          if (e) (void)hipEventDestroy(e);
     if (compute) (void)hipStreamDestroy(compute);
     if (xchg) (void)hipStreamDestroy(xchg);
     if (mat_host) (void)hipHostFree(mat_host);
@@ -138,6 +146,8 @@ struct Engine::Impl {
   size_t n = 0;
   Options opt;
   unsigned P = 1;
+  unsigned H = 1;   // sub-joins per step
+  unsigned HP = 1;  // buckets of the rank-level partition: bucket = destination rank * H + sub-join
   bool rccl = false;
   bool direct = false;
   std::vector<std::unique_ptr<Rank>> ranks;  // the LOCAL ranks
@@ -161,14 +171,14 @@ struct Engine::Impl {
       nccl_ok(ncclGroupStart(), "ncclGroupStart");
       for (auto &k : ranks) {
         set(*k);
-        nccl_ok(ncclAllGather(k->cnt_dev.as<uint64_t>() + rel * P, k->mat_dev.as<uint64_t>() + rel * P * P, P, ncclUint64,
+        nccl_ok(ncclAllGather(k->cnt_dev.as<uint64_t>() + rel * HP, k->mat_dev.as<uint64_t>() + rel * P * HP, HP, ncclUint64,
                               k->comm, k->xchg),
                 "ncclAllGather");
       }
       nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
       for (auto &k : ranks) {
         set(*k);
-        hip_ok(hipMemcpyAsync(k->mat_host + rel * P * P, k->mat_dev.as<uint64_t>() + rel * P * P, P * P * sizeof(uint64_t),
+        hip_ok(hipMemcpyAsync(k->mat_host + rel * P * HP, k->mat_dev.as<uint64_t>() + rel * P * HP, P * HP * sizeof(uint64_t),
                               hipMemcpyDeviceToHost, k->xchg),
                "hipMemcpyAsync");
       }
@@ -176,17 +186,22 @@ struct Engine::Impl {
       for (auto &src : ranks) {
         set(*src);
         for (auto &dst : ranks)
-          hip_ok(hipMemcpyAsync(dst->mat_host + rel * P * P + static_cast<size_t>(src->id) * P,
-                                src->cnt_dev.as<uint64_t>() + rel * P, P * sizeof(uint64_t), hipMemcpyDeviceToHost,
+          hip_ok(hipMemcpyAsync(dst->mat_host + rel * P * HP + static_cast<size_t>(src->id) * HP,
+                                src->cnt_dev.as<uint64_t>() + rel * HP, HP * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                 src->xchg),
                  "hipMemcpyAsync");
       }
     }
   }
 
-  // rows rank `q` sends to rank `r` in relation `rel`, from rank k's pinned matrix
-  static uint64_t cell(const Rank &k, unsigned P, unsigned rel, unsigned q, unsigned r) {
-    return k.mat_host[static_cast<size_t>(rel) * P * P + static_cast<size_t>(q) * P + r];
+  // rows rank `q` sends to rank `r` in sub-join `h` of relation `rel`, from rank k's pinned matrix
+  uint64_t cell(const Rank &k, unsigned rel, unsigned q, unsigned r, unsigned h) const {
+    return k.mat_host[static_cast<size_t>(rel) * P * HP + static_cast<size_t>(q) * HP + static_cast<size_t>(r) * H + h];
+  }
+  uint64_t cell_all(const Rank &k, unsigned rel, unsigned q, unsigned r) const {  // ... in all sub-joins together
+    uint64_t sum = 0;
+    for (unsigned h = 0; h < H; ++h) sum += cell(k, rel, q, r, h);
+    return sum;
   }
 
   // The gathered matrix decides every address and length of the exchange: before any send or receive is queued, check
@@ -196,12 +211,12 @@ struct Engine::Impl {
   void validate_matrix(const Rank &k, unsigned rel) const {
     // test hook: what a damaged gather would look like (one cell of the last local rank's matrix off by one)
     static const bool corrupt = [] { const char *e = std::getenv("DWARF_BENCH_PJOIN_CORRUPT_MATRIX"); return e && e[0] == '1'; }();
-    if (corrupt && planned && &k == ranks.back().get()) k.mat_host[static_cast<size_t>(rel) * P * P] += 1;
+    if (corrupt && planned && &k == ranks.back().get()) k.mat_host[static_cast<size_t>(rel) * P * HP] += 1;
     const size_t per = n / P;
     uint64_t all = 0, cols = 0;
     for (unsigned q = 0; q < P; ++q) {
       uint64_t row = 0;
-      for (unsigned r = 0; r < P; ++r) row += cell(k, P, rel, q, r);
+      for (unsigned r = 0; r < P; ++r) row += cell_all(k, rel, q, r);
       const uint64_t shard = (q == P - 1) ? n - static_cast<size_t>(q) * per : per;
       if (row != shard)
         fail("partitioned join: rank " + std::to_string(k.id) + " gathered a count matrix whose row " + std::to_string(q) +
@@ -210,15 +225,33 @@ struct Engine::Impl {
       all += row;
     }
     for (unsigned r = 0; r < P; ++r)
-      for (unsigned q = 0; q < P; ++q) cols += cell(k, P, rel, q, r);
+      for (unsigned q = 0; q < P; ++q) cols += cell_all(k, rel, q, r);
     if (all != n || cols != n) fail("partitioned join: the gathered count matrix does not add up to the relation's row count");
+  }
+
+  // largest radix-join workspace any sub-join of rank k needs (sizes as known so far; slack = the headroom plan() adds)
+  size_t radix_ws_need(const Rank &k, size_t slack_div) const {
+    size_t need = 0;
+    for (unsigned h = 0; h < H; ++h) {
+      const size_t r = k.sub_r[h] + (slack_div ? k.sub_r[h] / slack_div : 0), sv = k.sub_s[h] + (slack_div ? k.sub_s[h] / slack_div : 0);
+      need = std::max(need, dbhip_join_radix_workspace_bytes(r, sv));
+    }
+    return need;
   }
 
   void size_receives(unsigned rel) {
     for (auto &k : ranks) {
       validate_matrix(*k, rel);
       size_t total = 0;
-      for (unsigned q = 0; q < P; ++q) total += cell(*k, P, rel, q, k->id);
+      size_t *sub = rel == 0 ? k->sub_r : k->sub_s, *off = rel == 0 ? k->off_r : k->off_s;
+      for (unsigned h = 0; h < H; ++h) {
+        size_t rows = 0;
+        for (unsigned q = 0; q < P; ++q) rows += cell(*k, rel, q, k->id, h);
+        sub[h] = rows;
+        off[h] = total;
+        total += rows;
+      }
+      off[H] = total;
       (rel == 0 ? k->recv_r : k->recv_s) = total;
       DevMem &keys = rel == 0 ? k->rk : k->sk, &rids = rel == 0 ? k->rr : k->sr;
       if (total * 4 > keys.bytes || total * 4 > rids.bytes) {  // steady state never grows: plan() left headroom
@@ -228,8 +261,9 @@ struct Engine::Impl {
       }
       if (rel == 0) {
         // radix join: the build side's regions of the workspace depend on the build size alone; the probe side's size is
-        // only known after S's counts, so the workspace is re-checked then (rel == 1)
-        const size_t need = opt.radix_local ? dbhip_join_radix_workspace_bytes(total, k->recv_s) : dbhip_join_workspace_bytes(total);
+        // only known after S's counts (plan() has put the planning pass's sizes into sub_s), so the workspace is
+        // re-checked then (rel == 1)
+        const size_t need = opt.radix_local ? radix_ws_need(*k, 0) : dbhip_join_workspace_bytes(*std::max_element(k->sub_r, k->sub_r + H));
         if (need > k->join_ws.bytes || total * 4 > k->ids.bytes) {
           sync_all();
           k->join_ws.reserve(k->device, need + need / 16);
@@ -242,7 +276,7 @@ struct Engine::Impl {
           k->cnt.reserve(k->device, total * 4 + total / 16 * 4);
           k->out_rid.reserve(k->device, total * 4 + total / 16 * 4);
         }
-        if (opt.radix_local && dbhip_join_radix_workspace_bytes(k->recv_r, total) > k->join_ws.bytes) {
+        if (opt.radix_local && radix_ws_need(*k, 0) > k->join_ws.bytes) {
           // (steady state never gets here: plan() sized the workspace for both sides; growing it would lose the
           //  build side already partitioned into it, so this is a hard error rather than a silent re-run)
           fail("partitioned join: receive sizes changed between the planning pass and a step");
@@ -251,8 +285,8 @@ struct Engine::Impl {
     }
   }
 
-  // ---- exchange of one relation: bucket d of every rank goes to rank d ---------------------------------------------
-  void exchange(unsigned rel) {
+  // ---- exchange of sub-join h of one relation: bucket (d, h) of every rank goes to rank d -----------------------------
+  void exchange(unsigned rel, unsigned h) {
     if (rccl) nccl_ok(ncclGroupStart(), "ncclGroupStart");
     for (auto &kp : ranks) {
       Rank &me = *kp;
@@ -261,13 +295,18 @@ struct Engine::Impl {
       const uint32_t *src_r = (rel == 0 ? me.pr_r : me.pr_s).as<uint32_t>();
       uint32_t *dst_k = (rel == 0 ? me.rk : me.sk).as<uint32_t>();
       uint32_t *dst_r = (rel == 0 ? me.rr : me.sr).as<uint32_t>();
-      uint64_t send_off = 0, recv_off = 0;
-      const uint64_t recv_total = rel == 0 ? me.recv_r : me.recv_s;
+      const uint64_t recv_base = (rel == 0 ? me.off_r : me.off_s)[h], recv_end = (rel == 0 ? me.off_r : me.off_s)[h + 1];
       const uint64_t recv_cap = (rel == 0 ? me.rk : me.sk).bytes / 4;
+      uint64_t recv_off = recv_base;
       for (unsigned q = 0; q < P; ++q) {
-        const uint64_t send_cnt = cell(me, P, rel, me.id, q), recv_cnt = cell(me, P, rel, q, me.id);
+        // my buckets lie in bucket order b = rank * H + sub-join: bucket (q, h) starts behind all buckets before it
+        uint64_t send_off = 0;
+        for (unsigned r = 0; r < P; ++r)
+          for (unsigned g = 0; g < H; ++g)
+            if (r * H + g < q * H + h) send_off += cell(me, rel, me.id, r, g);
+        const uint64_t send_cnt = cell(me, rel, me.id, q, h), recv_cnt = cell(me, rel, q, me.id, h);
         // (validate_matrix has run in size_receives: these cannot fire unless the pinned matrix changed since)
-        if (send_off + send_cnt > me.n_local || recv_off + recv_cnt > recv_total || recv_total > recv_cap)
+        if (send_off + send_cnt > me.n_local || recv_off + recv_cnt > recv_end || recv_end > recv_cap)
           fail("partitioned join: exchange segment outside its buffer");
         static_assert(kPiece <= (1ull << 28), "one ncclSend/ncclRecv carries at most 2^28 elements (1 GiB)");
         const uint64_t piece = piece_elems();
@@ -286,14 +325,16 @@ struct Engine::Impl {
           Rank *peer = nullptr;
           for (auto &c : ranks)
             if (c->id == q) peer = c.get();
-          uint64_t peer_off = 0;  // where my segment starts on the peer: rows of the senders before me
-          for (unsigned w = 0; w < me.id; ++w) peer_off += cell(me, P, rel, w, q);
+          // where my segment starts on the peer: its sub-joins before h, then the senders before me inside sub-join h
+          uint64_t peer_off = 0;
+          for (unsigned g = 0; g < h; ++g)
+            for (unsigned w = 0; w < P; ++w) peer_off += cell(me, rel, w, q, g);
+          for (unsigned w = 0; w < me.id; ++w) peer_off += cell(me, rel, w, q, h);
           uint32_t *pk = (rel == 0 ? peer->rk : peer->sk).as<uint32_t>() + peer_off;
           uint32_t *pr = (rel == 0 ? peer->rr : peer->sr).as<uint32_t>() + peer_off;
           hip_ok(hipMemcpyPeerAsync(pk, peer->device, src_k + send_off, me.device, send_cnt * 4, me.xchg), "hipMemcpyPeerAsync");
           hip_ok(hipMemcpyPeerAsync(pr, peer->device, src_r + send_off, me.device, send_cnt * 4, me.xchg), "hipMemcpyPeerAsync");
         }
-        send_off += send_cnt;
         recv_off += recv_cnt;
       }
     }
@@ -303,8 +344,10 @@ struct Engine::Impl {
   void partition(Rank &k, unsigned rel) {
     set(k);
     const uint32_t *src = (rel == 0 ? k.build : k.probe).as<uint32_t>();
-    db_ok(dbhip_pjoin_partition_u32(src, k.n_local, k.lo, P, (rel == 0 ? k.pk_r : k.pk_s).as<uint32_t>(),
-                                    (rel == 0 ? k.pr_r : k.pr_s).as<uint32_t>(), k.cnt_dev.as<uint64_t>() + rel * P,
+    // HP buckets in rank-major order: floor(bucket / H) is the key's bucket among P (multiply-shift range reduction), so
+    // a rank still receives exactly the keys dbhip_check_pjoin_route_u32(parts = P) expects
+    db_ok(dbhip_pjoin_partition_u32(src, k.n_local, k.lo, HP, (rel == 0 ? k.pk_r : k.pk_s).as<uint32_t>(),
+                                    (rel == 0 ? k.pr_r : k.pr_s).as<uint32_t>(), k.cnt_dev.as<uint64_t>() + rel * HP,
                                     k.part_ws.p, k.part_ws_bytes, k.compute),
           "dbhip_pjoin_partition_u32");
   }
@@ -318,6 +361,17 @@ Engine::Engine(size_t n_total, const Options &opts) : impl_(new Impl) {
   if (m.P > 256) fail("partitioned join: at most 256 ranks");
   if (n_total > 0xFFFFFFFFull) fail("partitioned join: global row ids must fit 32 bits");
   m.direct = m.P == 1 && opts.direct_single;
+  {
+    unsigned h = opts.sub_joins;
+    if (h == 0) {
+      const char *e = std::getenv("DWARF_BENCH_PJOIN_SUBJOINS");
+      h = e ? static_cast<unsigned>(std::strtoul(e, nullptr, 10)) : 2u;
+    }
+    if (h != 1 && h != 2 && h != 4) fail("partitioned join: sub_joins must be 1, 2 or 4");
+    if (static_cast<size_t>(h) * m.P > 1024) h = 1;  // (the rank-level partition takes at most 1024 buckets)
+    m.H = m.direct ? 1u : h;
+    m.HP = m.H * m.P;
+  }
   int ndev = 0;
   hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
   if (ndev < 1) fail("partitioned join: no HIP device");
@@ -336,9 +390,11 @@ Engine::Engine(size_t n_total, const Options &opts) : impl_(new Impl) {
     hip_ok(hipSetDevice(k->device), "hipSetDevice");
     hip_ok(hipStreamCreateWithFlags(&k->compute, hipStreamNonBlocking), "hipStreamCreate");
     hip_ok(hipStreamCreateWithFlags(&k->xchg, hipStreamNonBlocking), "hipStreamCreate");
-    for (hipEvent_t *e : {&k->ev_start, &k->ev_part_r, &k->ev_part_s, &k->ev_cnt_r, &k->ev_cnt_s, &k->ev_x0, &k->ev_xr,
-                          &k->ev_xs, &k->ev_build0, &k->ev_build, &k->ev_probe0, &k->ev_done})
+    for (hipEvent_t *e : {&k->ev_start, &k->ev_part_r, &k->ev_part_s, &k->ev_cnt_r, &k->ev_cnt_s, &k->ev_build, &k->ev_done})
       hip_ok(hipEventCreate(e), "hipEventCreate");
+    for (auto *arr : {&k->ev_x0, &k->ev_x1, &k->ev_l0, &k->ev_l1})
+      for (auto &rel : *arr)
+        for (unsigned h = 0; h < m.H; ++h) hip_ok(hipEventCreate(&rel[h]), "hipEventCreate");
     const size_t per = n_total / m.P;
     k->lo = static_cast<size_t>(k->id) * per;
     k->n_local = (k->id == m.P - 1) ? n_total - k->lo : per;
@@ -353,12 +409,12 @@ Engine::Engine(size_t n_total, const Options &opts) : impl_(new Impl) {
       k->pr_r.reserve(k->device, col);
       k->pk_s.reserve(k->device, col);
       k->pr_s.reserve(k->device, col);
-      k->cnt_dev.reserve(k->device, 2 * m.P * sizeof(uint64_t));
-      k->mat_dev.reserve(k->device, 2 * static_cast<size_t>(m.P) * m.P * sizeof(uint64_t));
-      hip_ok(hipHostMalloc(reinterpret_cast<void **>(&k->mat_host), 2 * static_cast<size_t>(m.P) * m.P * sizeof(uint64_t),
+      k->cnt_dev.reserve(k->device, 2 * m.HP * sizeof(uint64_t));
+      k->mat_dev.reserve(k->device, 2 * static_cast<size_t>(m.P) * m.HP * sizeof(uint64_t));
+      hip_ok(hipHostMalloc(reinterpret_cast<void **>(&k->mat_host), 2 * static_cast<size_t>(m.P) * m.HP * sizeof(uint64_t),
                            hipHostMallocDefault),
              "hipHostMalloc");
-      k->part_ws_bytes = dbhip_pjoin_partition_workspace_bytes(k->n_local, m.P);
+      k->part_ws_bytes = dbhip_pjoin_partition_workspace_bytes(k->n_local, m.HP);
       k->part_ws.reserve(k->device, k->part_ws_bytes);
     }
     m.ranks.push_back(std::move(k));
@@ -398,6 +454,7 @@ Engine::~Engine() {
 }
 
 unsigned Engine::world() const { return impl_->P; }
+unsigned Engine::sub_joins() const { return impl_->H; }
 unsigned Engine::local_ranks() const { return static_cast<unsigned>(impl_->ranks.size()); }
 bool Engine::uses_rccl() const { return impl_->rccl; }
 unsigned Engine::rccl_ranks_seen() const {
@@ -414,6 +471,8 @@ void Engine::plan() {
   if (m.direct) {
     Rank &k = m.local(0);
     k.recv_r = k.recv_s = k.n_local;
+    k.sub_r[0] = k.sub_s[0] = k.n_local;
+    k.off_r[1] = k.off_s[1] = k.n_local;
     k.join_ws.reserve(k.device, m.opt.radix_local ? dbhip_join_radix_workspace_bytes(k.n_local, k.n_local)
                                                    : dbhip_join_workspace_bytes(k.n_local));
     k.ids.reserve(k.device, k.n_local * 4);
@@ -435,11 +494,16 @@ void Engine::plan() {
   m.gather_counts(0);
   m.gather_counts(1);
   m.sync_all();
-  for (auto &k : m.ranks) {  // both receive sizes at once: the radix join's workspace depends on both
-    k->recv_s = 0;
-    for (unsigned q = 0; q < m.P; ++q) k->recv_s += Impl::cell(*k, m.P, 1, q, k->id);
-    k->recv_s += k->recv_s / 16;  // the headroom the buffers get
-  }
+  for (auto &k : m.ranks)  // both relations' sub-join sizes at once: a radix join's workspace depends on both of its sides
+    for (unsigned h = 0; h < m.H; ++h) {
+      k->sub_r[h] = k->sub_s[h] = 0;
+      for (unsigned q = 0; q < m.P; ++q) {
+        k->sub_r[h] += m.cell(*k, 0, q, k->id, h);
+        k->sub_s[h] += m.cell(*k, 1, q, k->id, h);
+      }
+    }
+  for (auto &k : m.ranks)
+    if (m.opt.radix_local) k->join_ws.reserve(k->device, m.radix_ws_need(*k, 16));  // the headroom the buffers get
   m.size_receives(0);
   m.size_receives(1);
   m.planned = true;
@@ -501,14 +565,56 @@ StepTimes Engine::step() {
     hip_ok(hipEventSynchronize(k->ev_cnt_r), "hipEventSynchronize");  // host wait 1: R's receive sizes
   }
   m.size_receives(0);
+  // one send/recv group on the exchange stream (every local rank's), bracketed by its events
+  auto queue_exchange = [&](unsigned rel, unsigned h) {
+    for (auto &k : m.ranks) {
+      m.set(*k);
+      hip_ok(hipEventRecord(k->ev_x0[rel][h], k->xchg), "hipEventRecord");
+    }
+    m.exchange(rel, h);
+    for (auto &k : m.ranks) {
+      m.set(*k);
+      hip_ok(hipEventRecord(k->ev_x1[rel][h], k->xchg), "hipEventRecord");
+    }
+  };
+  // the local work on sub-join h of one relation, behind its exchange.  Without RCCL a rank's receive buffers are filled
+  // by the OTHER ranks' streams: wait for every sender.
+  auto queue_local = [&](unsigned rel, unsigned h) {
+    for (auto &k : m.ranks) {
+      m.set(*k);
+      if (m.rccl) {
+        hip_ok(hipStreamWaitEvent(k->compute, k->ev_x1[rel][h], 0), "hipStreamWaitEvent");
+      } else {
+        for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_x1[rel][h], 0), "hipStreamWaitEvent");
+      }
+      hip_ok(hipEventRecord(k->ev_l0[rel][h], k->compute), "hipEventRecord");
+      uint32_t *rk = k->rk.as<uint32_t>() + k->off_r[h], *rr = k->rr.as<uint32_t>() + k->off_r[h];
+      uint32_t *sk = k->sk.as<uint32_t>() + k->off_s[h], *sr = k->sr.as<uint32_t>() + k->off_s[h];
+      uint32_t *ids = k->ids.as<uint32_t>() + k->off_r[h];
+      uint32_t *pos = k->pos.as<uint32_t>() + k->off_s[h], *cnt = k->cnt.as<uint32_t>() + k->off_s[h];
+      uint32_t *orid = k->out_rid.as<uint32_t>() + k->off_s[h];
+      if (rel == 0) {
+        if (m.opt.radix_local)  // the received build pairs into the local partitions (the probe side's size is not known yet
+                                // in sub-join 0: the build side's part of the workspace does not depend on it)
+          db_ok(dbhip_join_radix_partition_u32(0, rk, rr, k->sub_r[h], k->sub_r[h], 0, k->join_ws.p, k->join_ws.bytes, k->compute),
+                "dbhip_join_radix_partition_u32");
+        else
+          db_ok(dbhip_join_build_pairs_u32(rk, rr, k->sub_r[h], ids, k->join_ws.p, k->join_ws.bytes, k->compute),
+                "dbhip_join_build_pairs_u32");
+      } else if (m.opt.radix_local) {
+        db_ok(dbhip_join_radix_partition_u32(1, sk, sr, k->sub_s[h], k->sub_r[h], k->sub_s[h], k->join_ws.p, k->join_ws.bytes,
+                                             k->compute), "dbhip_join_radix_partition_u32");
+        db_ok(dbhip_join_radix_match_u32(k->sub_r[h], k->sub_s[h], ids, orid, pos, cnt, k->join_ws.p, k->join_ws.bytes, k->compute),
+              "dbhip_join_radix_match_u32");
+      } else {
+        db_ok(dbhip_join_probe_u32(sk, k->sub_s[h], k->join_ws.p, k->sub_r[h], pos, cnt, k->compute), "dbhip_join_probe_u32");
+      }
+      hip_ok(hipEventRecord(k->ev_l1[rel][h], k->compute), "hipEventRecord");
+    }
+  };
+  queue_exchange(0, 0);
   for (auto &k : m.ranks) {
     m.set(*k);
-    hip_ok(hipEventRecord(k->ev_x0, k->xchg), "hipEventRecord");
-  }
-  m.exchange(0);
-  for (auto &k : m.ranks) {
-    m.set(*k);
-    hip_ok(hipEventRecord(k->ev_xr, k->xchg), "hipEventRecord");
     hip_ok(hipStreamWaitEvent(k->xchg, k->ev_part_s, 0), "hipStreamWaitEvent");
   }
   m.gather_counts(1);
@@ -516,55 +622,28 @@ StepTimes Engine::step() {
     m.set(*k);
     hip_ok(hipEventRecord(k->ev_cnt_s, k->xchg), "hipEventRecord");
   }
-  // ---- build on the received R pairs (while S's counts travel and S goes onto the links).  Without RCCL a rank's
-  // receive buffers are filled by the OTHER ranks' streams: wait for every sender.
+  // ---- sub-join 0's build side locally (while S's counts travel and S goes onto the links)
+  queue_local(0, 0);
   for (auto &k : m.ranks) {
     m.set(*k);
-    if (m.rccl) {
-      hip_ok(hipStreamWaitEvent(k->compute, k->ev_xr, 0), "hipStreamWaitEvent");
-    } else {
-      for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xr, 0), "hipStreamWaitEvent");
-    }
-    hip_ok(hipEventRecord(k->ev_build0, k->compute), "hipEventRecord");
-    if (m.opt.radix_local)  // the received build pairs into the local partitions (the probe side's size is not known yet:
-                            // the build side's part of the workspace does not depend on it)
-      db_ok(dbhip_join_radix_partition_u32(0, k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->recv_r, 0, k->join_ws.p,
-                                           k->join_ws.bytes, k->compute), "dbhip_join_radix_partition_u32");
-    else
-      db_ok(dbhip_join_build_pairs_u32(k->rk.as<uint32_t>(), k->rr.as<uint32_t>(), k->recv_r, k->ids.as<uint32_t>(),
-                                       k->join_ws.p, k->join_ws.bytes, k->compute),
-            "dbhip_join_build_pairs_u32");
     hip_ok(hipEventRecord(k->ev_build, k->compute), "hipEventRecord");
-  }
-  for (auto &k : m.ranks) {
-    m.set(*k);
     hip_ok(hipEventSynchronize(k->ev_cnt_s), "hipEventSynchronize");  // host wait 2: S's receive sizes
   }
   m.size_receives(1);
-  m.exchange(1);
-  for (auto &k : m.ranks) {
-    m.set(*k);
-    hip_ok(hipEventRecord(k->ev_xs, k->xchg), "hipEventRecord");
+  // ---- the links carry S0, R1, S1, ... one group after the other; the compute stream follows one sub-join behind:
+  // what is left to do behind the LAST group is one sub-join's probe side (1 / H of the rows)
+  queue_exchange(1, 0);
+  for (unsigned h = 1; h < m.H; ++h) {
+    queue_exchange(0, h);
+    queue_exchange(1, h);
+  }
+  queue_local(1, 0);
+  for (unsigned h = 1; h < m.H; ++h) {
+    queue_local(0, h);
+    queue_local(1, h);
   }
   for (auto &k : m.ranks) {
     m.set(*k);
-    if (m.rccl) {
-      hip_ok(hipStreamWaitEvent(k->compute, k->ev_xs, 0), "hipStreamWaitEvent");
-    } else {
-      for (auto &s : m.ranks) hip_ok(hipStreamWaitEvent(k->compute, s->ev_xs, 0), "hipStreamWaitEvent");
-    }
-    hip_ok(hipEventRecord(k->ev_probe0, k->compute), "hipEventRecord");
-    if (m.opt.radix_local) {
-      db_ok(dbhip_join_radix_partition_u32(1, k->sk.as<uint32_t>(), k->sr.as<uint32_t>(), k->recv_s, k->recv_r, k->recv_s,
-                                           k->join_ws.p, k->join_ws.bytes, k->compute), "dbhip_join_radix_partition_u32");
-      db_ok(dbhip_join_radix_match_u32(k->recv_r, k->recv_s, k->ids.as<uint32_t>(), k->out_rid.as<uint32_t>(),
-                                       k->pos.as<uint32_t>(), k->cnt.as<uint32_t>(), k->join_ws.p, k->join_ws.bytes, k->compute),
-            "dbhip_join_radix_match_u32");
-    } else {
-      db_ok(dbhip_join_probe_u32(k->sk.as<uint32_t>(), k->recv_s, k->join_ws.p, k->recv_r, k->pos.as<uint32_t>(),
-                                 k->cnt.as<uint32_t>(), k->compute),
-            "dbhip_join_probe_u32");
-    }
     hip_ok(hipEventRecord(k->ev_done, k->compute), "hipEventRecord");
   }
   for (auto &k : m.ranks) {
@@ -577,11 +656,18 @@ StepTimes Engine::step() {
   for (auto &k : m.ranks) {
     m.set(*k);
     t.partition = std::max(t.partition, span_us(k->ev_start, k->ev_part_s));
-    t.exchange = std::max(t.exchange, span_us(k->ev_x0, k->ev_xs));
-    t.exchange_r = std::max(t.exchange_r, span_us(k->ev_x0, k->ev_xr));
-    t.exchange_s = std::max(t.exchange_s, span_us(k->ev_cnt_s, k->ev_xs));
-    t.build = std::max(t.build, span_us(k->ev_build0, k->ev_build));
-    t.probe = std::max(t.probe, span_us(k->ev_probe0, k->ev_done));
+    t.exchange = std::max(t.exchange, span_us(k->ev_x0[0][0], k->ev_x1[1][m.H - 1]));
+    double xr = 0, xs = 0, lb = 0, lp = 0;
+    for (unsigned h = 0; h < m.H; ++h) {
+      xr += span_us(k->ev_x0[0][h], k->ev_x1[0][h]);
+      xs += span_us(k->ev_x0[1][h], k->ev_x1[1][h]);
+      lb += span_us(k->ev_l0[0][h], k->ev_l1[0][h]);
+      lp += span_us(k->ev_l0[1][h], k->ev_l1[1][h]);
+    }
+    t.exchange_r = std::max(t.exchange_r, xr);
+    t.exchange_s = std::max(t.exchange_s, xs);
+    t.build = std::max(t.build, lb);
+    t.probe = std::max(t.probe, lp);
   }
   return t;
 }
@@ -604,69 +690,77 @@ CheckReport Engine::check() {
       int32_t *sums = reinterpret_cast<int32_t *>(res + 32);
       for (int c = 0; c < 8; ++c)
         db_ok(dbhip_reduce_sum_i32(static_cast<const int32_t *>(cols[c]), lens[c], sums + c, s), "dbhip_reduce_sum_i32");
-      // received pairs are what the generator produced for their global row id; received keys hash to this rank
+      // received pairs are what the generator produced for their global row id
       db_ok(dbhip_check_gen_uniform_u32(k.rk.as<uint32_t>(), k.rr.as<uint32_t>(), k.recv_r, m.opt.build_seed, 0, 0, key_hi,
                                         res + 0, s), "dbhip_check_gen_uniform_u32");
       db_ok(dbhip_check_gen_uniform_u32(k.sk.as<uint32_t>(), k.sr.as<uint32_t>(), k.recv_s, m.opt.probe_seed, 0, 0, key_hi,
                                         res + 1, s), "dbhip_check_gen_uniform_u32");
-      db_ok(dbhip_check_pjoin_route_u32(k.rk.as<uint32_t>(), k.recv_r, m.P, k.id, res + 2, s), "dbhip_check_pjoin_route_u32");
-      db_ok(dbhip_check_pjoin_route_u32(k.sk.as<uint32_t>(), k.recv_s, m.P, k.id, res + 3, s), "dbhip_check_pjoin_route_u32");
     }
-    // per probe row: count == multiplicity of the key among the build keys this rank joined (sorted copy, binary
-    // search), id range inside the id buffer, sampled ids carry the key (regenerated from the GLOBAL row id)
-    DevMem sorted, tmp, sort_ws;
-    sorted.reserve(k.device, k.recv_r * 4);
-    tmp.reserve(k.device, k.recv_r * 4);
-    const size_t sort_bytes = dbhip_radix_sort_workspace_bytes(k.recv_r, 8);
-    sort_ws.reserve(k.device, sort_bytes);
-    if (k.recv_r) {
-      hip_ok(hipMemcpyAsync(sorted.p, bkeys, k.recv_r * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-      db_ok(dbhip_radix_sort_u32(sorted.as<uint32_t>(), tmp.as<uint32_t>(), k.recv_r, 8, sort_ws.p, sort_ws.bytes, s),
-            "dbhip_radix_sort_u32");
-    }
-    // radix local join: results come in the probe side's partition order with their row ids: the probe keys are
-    // regenerated in that order, and the row ids must be exactly the received ones (multiset fingerprint / permutation)
-    DevMem pk_result, perm_ws;
-    const uint32_t *pk_aligned = pkeys;
-    if (m.opt.radix_local) {
-      pk_result.reserve(k.device, k.recv_s * 4);
-      db_ok(dbhip_gen_uniform_at_u32(pk_result.as<uint32_t>(), k.out_rid.as<uint32_t>(), k.recv_s, m.opt.probe_seed, 0, key_hi, s),
-            "dbhip_gen_uniform_at_u32");
-      pk_aligned = pk_result.as<uint32_t>();
-      if (m.direct) {
-        const size_t pb = dbhip_check_permutation_workspace_bytes(k.recv_s);
-        perm_ws.reserve(k.device, pb);
-        db_ok(dbhip_check_permutation_u32(k.out_rid.as<uint32_t>(), k.recv_s, res + 8, perm_ws.p, perm_ws.bytes, s),
-              "dbhip_check_permutation_u32");
-      } else {
-        db_ok(dbhip_check_sorted_u32(k.out_rid.as<uint32_t>(), k.recv_s, 0, res + 8, s), "dbhip_check_sorted_u32");
-        db_ok(dbhip_check_sorted_u32(k.sr.as<uint32_t>(), k.recv_s, 0, res + 12, s), "dbhip_check_sorted_u32");
-      }
-    }
-    if (m.direct)  // local row indices: the key of an id is a lookup
-      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pk_aligned, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
-                                 k.ids.as<uint32_t>(), bkeys, 0, 0, 0, res + 4, s), "dbhip_check_join_u32");
-    else
-      db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), k.recv_r, pk_aligned, k.recv_s, k.pos.as<uint32_t>(), k.cnt.as<uint32_t>(),
-                                 k.ids.as<uint32_t>(), nullptr, m.opt.build_seed, 0, key_hi, res + 4, s), "dbhip_check_join_u32");
     hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize");
-    const auto h = d2h<uint64_t>(res, 40, k.device);
+    std::vector<uint64_t> h = d2h<uint64_t>(res, 40, k.device);
     if (!m.direct) {
       rep.bad_pairs += h[0] + h[1];
-      rep.bad_route += h[2] + h[3];
       const uint32_t *sums = reinterpret_cast<const uint32_t *>(h.data() + 32);
       for (int c = 0; c < 4; ++c) {
         rep.sent_sum[c] += sums[c];
         rep.recv_sum[c] += sums[4 + c];
       }
-      rep.sent_rows += 2 * k.n_local - Impl::cell(k, m.P, 0, k.id, k.id) - Impl::cell(k, m.P, 1, k.id, k.id);
+      rep.sent_rows += 2 * k.n_local - m.cell_all(k, 0, k.id, k.id) - m.cell_all(k, 1, k.id, k.id);
     }
-    rep.bad_rows += h[4];
-    if (m.opt.radix_local) {  // the result's row ids are the received ones, each once
-      if (m.direct) rep.bad_rows += h[8];
-      else if (h[9] != h[13] || h[10] != h[14]) rep.bad_rows += k.recv_s ? k.recv_s : 1;
+    // ---- per sub-join: routing, then per probe row count == multiplicity of the key among the build keys this rank
+    // joined in this sub-join (sorted copy, binary search), id range inside the id buffer, sampled ids carry the key
+    // (regenerated from the GLOBAL row id)
+    for (unsigned sj = 0; sj < m.H; ++sj) {
+      const size_t nr = k.sub_r[sj], ns = k.sub_s[sj], o_r = k.off_r[sj], o_s = k.off_s[sj];
+      if (!m.direct) {  // received keys hash to this rank AND to this sub-join: bucket rank * H + sub-join of HP
+        db_ok(dbhip_check_pjoin_route_u32(bkeys + o_r, nr, m.HP, k.id * m.H + sj, res + 2, s), "dbhip_check_pjoin_route_u32");
+        db_ok(dbhip_check_pjoin_route_u32(pkeys + o_s, ns, m.HP, k.id * m.H + sj, res + 3, s), "dbhip_check_pjoin_route_u32");
+      }
+      DevMem sorted, tmp, sort_ws;
+      sorted.reserve(k.device, nr * 4);
+      tmp.reserve(k.device, nr * 4);
+      const size_t sort_bytes = dbhip_radix_sort_workspace_bytes(nr, 8);
+      sort_ws.reserve(k.device, sort_bytes);
+      if (nr) {
+        hip_ok(hipMemcpyAsync(sorted.p, bkeys + o_r, nr * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        db_ok(dbhip_radix_sort_u32(sorted.as<uint32_t>(), tmp.as<uint32_t>(), nr, 8, sort_ws.p, sort_ws.bytes, s),
+              "dbhip_radix_sort_u32");
+      }
+      // radix local join: results come in the probe side's partition order with their row ids: the probe keys are
+      // regenerated in that order, and the row ids must be exactly the received ones (multiset fingerprint / permutation)
+      DevMem pk_result, perm_ws;
+      const uint32_t *pk_aligned = pkeys + o_s;
+      const uint32_t *orid = k.out_rid.as<uint32_t>() + o_s;
+      if (m.opt.radix_local) {
+        pk_result.reserve(k.device, ns * 4);
+        db_ok(dbhip_gen_uniform_at_u32(pk_result.as<uint32_t>(), orid, ns, m.opt.probe_seed, 0, key_hi, s), "dbhip_gen_uniform_at_u32");
+        pk_aligned = pk_result.as<uint32_t>();
+        if (m.direct) {
+          const size_t pb = dbhip_check_permutation_workspace_bytes(ns);
+          perm_ws.reserve(k.device, pb);
+          db_ok(dbhip_check_permutation_u32(orid, ns, res + 8, perm_ws.p, perm_ws.bytes, s), "dbhip_check_permutation_u32");
+        } else {
+          db_ok(dbhip_check_sorted_u32(orid, ns, 0, res + 8, s), "dbhip_check_sorted_u32");
+          db_ok(dbhip_check_sorted_u32(k.sr.as<uint32_t>() + o_s, ns, 0, res + 12, s), "dbhip_check_sorted_u32");
+        }
+      }
+      const uint32_t *pos = k.pos.as<uint32_t>() + o_s, *cnt = k.cnt.as<uint32_t>() + o_s, *ids = k.ids.as<uint32_t>() + o_r;
+      if (m.direct)  // local row indices: the key of an id is a lookup
+        db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), nr, pk_aligned, ns, pos, cnt, ids, bkeys, 0, 0, 0, res + 4, s),
+              "dbhip_check_join_u32");
+      else
+        db_ok(dbhip_check_join_u32(sorted.as<uint32_t>(), nr, pk_aligned, ns, pos, cnt, ids, nullptr, m.opt.build_seed, 0, key_hi,
+                                   res + 4, s), "dbhip_check_join_u32");
+      hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize");
+      h = d2h<uint64_t>(res, 40, k.device);
+      if (!m.direct) rep.bad_route += h[2] + h[3];
+      rep.bad_rows += h[4];
+      if (m.opt.radix_local) {  // the result's row ids are the received ones, each once
+        if (m.direct) rep.bad_rows += h[8];
+        else if (h[9] != h[13] || h[10] != h[14]) rep.bad_rows += ns ? ns : 1;
+      }
+      rep.matches += h[5];
     }
-    rep.matches += h[5];
     rep.recv_build += k.recv_r;
     rep.recv_probe += k.recv_s;
   }
@@ -719,6 +813,9 @@ Engine::HostShard Engine::download(unsigned i) const {
   h.pos = d2h<uint32_t>(k.pos.p, k.recv_s, k.device);
   h.cnt = d2h<uint32_t>(k.cnt.p, k.recv_s, k.device);
   h.ids = d2h<uint32_t>(k.ids.p, k.recv_r, k.device);
+  // every sub-join wrote positions relative to its own id range: make them positions in the rank's whole id buffer
+  for (unsigned sj = 1; sj < m.H; ++sj)
+    for (size_t i = k.off_s[sj]; i < k.off_s[sj + 1]; ++i) h.pos[i] += static_cast<uint32_t>(k.off_r[sj]);
   return h;
 }
 

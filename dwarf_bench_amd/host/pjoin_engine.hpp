@@ -38,6 +38,11 @@ struct Options {
   bool radix_local = true;     // local join = the radix join (both received sides partitioned alike, fused LDS build +
                                // probe, no table in HBM); false: build + row-ordered probe (the first implementation)
   uint64_t build_seed = 42, probe_seed = 43;  // columns: key_i = mix64(seed, i) % n_total (SURVEY 8d join regime)
+  // SUB-JOINS (round 4): every rank's rows are cut by one or two more bits of the rank hash into `sub_joins` (1, 2 or 4)
+  // independent joins — equal keys share all hash bits — whose exchanges follow each other on the links while the local
+  // join of the one before runs: the work that can only start behind the LAST exchange (local partition of the last
+  // relation to arrive + match) shrinks to 1 / sub_joins of what it is for one join.  0: DWARF_BENCH_PJOIN_SUBJOINS or 2.
+  unsigned sub_joins = 0;
 };
 
 struct StepTimes {  // microseconds; phases are device-event spans (max over the local ranks) and overlap by design
@@ -74,6 +79,7 @@ class Engine {
   bool conserved(const CheckReport &local);
 
   unsigned world() const;
+  unsigned sub_joins() const;  // what Options::sub_joins came to (1 in the direct one-GPU mode)
   unsigned local_ranks() const;
   bool uses_rccl() const;
   // ranks RCCL itself reports for the first local rank's communicator (ncclCommCount; 0 without RCCL): what a reader of

@@ -2,13 +2,16 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dwarf_bench_amd import ops
-n = 1 << 26
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ab import times, dropmax
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+n = 1 << lg
 build = ops.gen_uniform_u32(n, 42, 0, n - 1)
 probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
-plan = ops.HashJoin(n, n)
-plan.build(build)
-torch.cuda.synchronize()
-print("header words 28..40 after build:", plan.ws[28 * 4: 40 * 4].view(torch.int32).tolist() if plan.ws.dtype == torch.uint8 else plan.ws.view(torch.int32)[28:40].tolist())
-plan.probe(probe)
-torch.cuda.synchronize()
-print("after probe:", plan.ws.view(torch.int32)[28:40].tolist() if plan.ws.dtype != torch.uint8 else plan.ws[28 * 4: 40 * 4].view(torch.int32).tolist())
+ids = torch.arange(n, device="cuda", dtype=torch.int64).to(torch.int32)
+rj = ops.RadixJoin(n, n)
+for name, rid in (("row ids generated", None), ("row ids as a column", ids)):
+    pb = dropmax(times(lambda: rj.partition_build(build, rid), 7, warm=1))
+    pp = dropmax(times(lambda: rj.partition_probe(probe, rid), 7, warm=1))
+    m = dropmax(times(rj.match, 7, warm=1))
+    print(f"2^{lg} {name:22s}: partition build side {pb:8.1f} us, probe side {pp:8.1f} us, match {m:8.1f} us", flush=True)
