@@ -68,6 +68,23 @@ def test_partitioned_join_dwarf(gpus, env):
     assert f"exchange by {want}" in r.stdout
 
 
+@pytest.mark.parametrize("sub_joins", ["1", "2", "4"])
+@pytest.mark.parametrize("gpus", ["1", "3", "8"])
+def test_partitioned_join_pipelined_sub_joins(gpus, sub_joins):
+    """The engine cuts a step into 1, 2 (default) or 4 independent sub-joins by more bits of the rank hash — their
+    exchanges follow each other on the links while the sub-join before is joined locally (host/pjoin_engine.hpp
+    Options::sub_joins).  Every variant must deliver every probe row once with the right count and ids that carry its key
+    (host-side check at these sizes, on top of conservation / generator / routing-to-rank-AND-sub-join on the device),
+    ragged shards and n < ranks * sub-joins included."""
+    import os
+    r = _run(["PartitionedJoinHip", "--device=hip", "--gpus", gpus, "--iterations", "2", "--input_size", "7", "1000", "300007",
+              "2097152"], env={**os.environ, "DWARF_BENCH_PJOIN_SUBJOINS": sub_joins})
+    assert r.returncode == 0, r.stderr
+    assert "ncorrect results" not in r.stderr and "Caught exception" not in r.stderr, r.stderr
+    assert r.stdout.count("Build time:") == 2 * 4
+    assert (f"{sub_joins} pipelined sub-joins" in r.stdout) == (sub_joins != "1")
+
+
 def test_baseline_plumbing_config_csv(tmp_path):
     """BASELINE configs[0] on the HIP device: TwoPassScan --input_size=1024 --iterations=9 -> 9 valid rows,
     reference CSV schema (common/result.cpp:59-91), appended on a second run."""
