@@ -21,7 +21,7 @@ PartitionedJoinHip dwarf (libdbench.so, one rank per process, RCCL called from C
 exchange and of the result in the warm-up) and, under "pjoin.torch_distributed_host", on the torch.distributed host —
 each with its single-GPU time taken in this run on rank 0, i.e. the speed-up over one GPU is in the line itself.  The
 section runs in CHILD processes (every rank starts `bench.py --pjoin-child`, own process group one port up): a leg that
-hangs is cut by a watchdog (DBENCH_PJOIN_DEADLINE_S, default 900 s), a leg that takes its process down (a GPU memory
+hangs is cut by a watchdog (DBENCH_PJOIN_DEADLINE_S, default 600 s), a leg that takes its process down (a GPU memory
 fault aborts the process) costs `pjoin` an `error` entry, never the contract line (tests/test_gpu_bench_launcher.py).
 Rehearsal knobs (not for reported numbers): DBENCH_BACKEND=gloo lets several ranks share one GPU (the C++ RCCL leg
 is skipped), DBENCH_PJOIN_LOG2 shrinks the partitioned join.
@@ -613,7 +613,7 @@ def pjoin_section(args, dist, rank, world, local, barrier, out):
     torch.cuda.empty_cache()
     pj_steps, pj_warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
     pj_log2 = int(os.environ.get("DBENCH_PJOIN_LOG2", "30"))
-    dog = _Watchdog(int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")), rank, out)
+    dog = _Watchdog(int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "600")), rank, out)
     section = {"metric": f"Mrows/s, radix-partitioned hash join 2^{pj_log2} x 2^{pj_log2} (build+probe rows / s, all GPUs)",
                "scaling": "strong", "n_gpus": n_gpus, "steps": pj_steps, "warmup": pj_warm}
     if rank == 0:
@@ -688,7 +688,7 @@ def run_pjoin_children(args, rank):
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
     # under torch.distributed.run the ranks are clients of the launcher's store; the children's rank 0 must host its own
     env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
-    deadline = int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "900")) + 60
+    deadline = int(os.environ.get("DBENCH_PJOIN_DEADLINE_S", "600")) + 60
     cmd = [sys.executable, os.path.abspath(__file__), "--pjoin-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup)]
     print(f"[bench] rank {rank}: starting the partitioned-join child (port {env['MASTER_PORT']}, deadline {deadline} s)", file=sys.stderr, flush=True)
