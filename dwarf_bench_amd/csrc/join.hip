@@ -190,9 +190,7 @@ extern "C" int dbhip_join_radix_u32(const uint32_t *build_keys, const uint32_t *
 }
 
 extern "C" size_t dbhip_ujoin_workspace_bytes(size_t n_build) {
-  if (jl_use_ujoin(n_build)) return jl_layout(n_build).spill_off;  // radix-partitioned build, LDS sub-tables (join_lds.hip);
-                                                                     // no spill pool: unique keys overfill a sub-table only
-                                                                     // when constructed to, and this join then says so
+  if (jl_use_ujoin(n_build)) return jl_layout(n_build).total;  // radix-partitioned build, LDS sub-tables (join_lds.hip)
   return align_up(kWsHeader + 2 * join_capacity(n_build) * sizeof(unsigned), kWsAlign);
 }
 

@@ -1672,18 +1672,67 @@ __global__ __launch_bounds__(kJlThreads) void jl_probe_kernel(const unsigned *__
 // One workgroup per partition: ds_cmpst claims the key's slot, the claimer stores its payload next to it (a
 // duplicate build key keeps the first claimer's payload: keys are unique by contract, join/join.cpp:13-16), the
 // sub-table goes out as 8-byte slots {key, payload}.  Probe: one 8-byte gather per step.
+// A partition of more than kJlSubSlots (unique) keys — keys constructed against the hash — goes to the spill pool as well
+// (round 4): the workgroup builds an open-addressing {key -> payload} table for it there (jl_spill_partition's pool and
+// directory; the position array holds the payloads), and publishes the sub-table as an empty one whose slots carry
+// payload 0 instead of the sentinel: the mark the probe looks for on a miss.
+__device__ __noinline__ void jl_uspill_partition(const JlSpill sp, const u32x2 *__restrict__ rows, size_t lo, size_t hi, unsigned part,
+                                                 unsigned *status) {
+  constexpr unsigned kT = kJlBuildThreads;
+  __shared__ unsigned s_base;
+  const unsigned tid = threadIdx.x;
+  const unsigned cap = static_cast<unsigned>(jl_spill_cap(hi - lo));
+  __syncthreads();
+  if (tid == 0) s_base = atomicAdd(status + kJlHdrSpillPool, cap);
+  __syncthreads();
+  const unsigned base = s_base;
+  if (static_cast<unsigned long long>(base) + cap > sp.pool) {  // (cannot happen: the pool holds every partition that can spill)
+    if (tid == 0) atomicOr(status, DBHIP_DEV_TABLE_FULL);
+    return;
+  }
+  unsigned *keys = sp.keys() + base, *vals = sp.pos() + base;
+  for (unsigned i = tid; i < cap; i += kT) keys[i] = kEmptyKey;
+  __threadfence();
+  __syncthreads();
+  for (size_t i = lo + tid; i < hi; i += kT) {
+    const u32x2 row = rows[i];
+    if (row.x == kEmptyKey) {
+      atomicOr(status, DBHIP_DEV_KEY_RANGE);
+      continue;
+    }
+    unsigned sl = jl_spill_home(row.x, cap);
+    while (true) {  // (cap > rows: an empty slot exists)
+      const unsigned k = atomicCAS(&keys[sl], kEmptyKey, row.x);
+      if (k == kEmptyKey) {  // the claimer's payload stays (a duplicate build key keeps the first claimer's: join.cpp:13-16)
+        __hip_atomic_store(&vals[sl], row.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if (k == row.x) break;
+      sl = sl + 1 == cap ? 0u : sl + 1;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) sp.dir()[part] = u32x2{base + 1u, cap};
+}
+
 __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsigned *__restrict__ pkeys,
                                                                     const unsigned *__restrict__ prids,
                                                                     const unsigned long long *__restrict__ starts,
-                                                                    u32x2 *__restrict__ table, unsigned *status) {
+                                                                    u32x2 *__restrict__ table, unsigned *status, JlSpill spill) {
   __shared__ unsigned lk[kJlSubSlots];
   __shared__ unsigned lv[kJlSubSlots];
+  __shared__ unsigned s_full;
   const unsigned tid = threadIdx.x;
   const size_t part = blockIdx.x;
   const size_t lo = starts[part], hi = starts[part + 1];
   for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) {
     lk[i] = kEmptyKey;
     lv[i] = kEmptyKey;
+  }
+  if (tid == 0) {
+    s_full = 0;
+    spill.dir()[part] = u32x2{0u, 0u};  // "not spilled"
   }
   __syncthreads();
   for (size_t i = lo + tid; i < hi; i += kJlBuildThreads) {
@@ -1702,14 +1751,19 @@ __global__ __launch_bounds__(kJlBuildThreads) void jl_ubuild_kernel(const unsign
       }
       if (old == key) break;
       s = jl_next_slot(s);
-      if (tries + 1 >= kJlSubSlots) {
-        atomicOr(status, DBHIP_DEV_TABLE_FULL);
+      if (tries + 1 >= kJlSubSlots) {  // more keys than slots: the partition goes to the spill pool
+        s_full = 1u;
         break;
       }
     }
   }
   __syncthreads();
   u32x2 *dst = table + part * kJlSubSlots;
+  if (s_full) {  // (uniform)
+    jl_uspill_partition(spill, reinterpret_cast<const u32x2 *>(pkeys), lo, hi, static_cast<unsigned>(part), status);
+    for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) __builtin_nontemporal_store(u32x2{kEmptyKey, 0u}, dst + i);
+    return;
+  }
   for (unsigned i = tid; i < kJlSubSlots; i += kJlBuildThreads) __builtin_nontemporal_store(u32x2{lk[i], lv[i]}, dst + i);
 }
 
@@ -1718,8 +1772,9 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
                                                                const u32x2 *__restrict__ table, unsigned parts,
                                                                unsigned *__restrict__ out_key,
                                                                unsigned *__restrict__ out_bval,
-                                                               unsigned *__restrict__ out_pval) {
+                                                               unsigned *__restrict__ out_pval, JlSpill spill) {
   const size_t stride = static_cast<size_t>(gridDim.x) * kJlThreads;
+  unsigned marked = 0;  // a miss of this thread ended on an empty slot of a spilled partition's sub-table (payload 0, not the sentinel)
   for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
     const unsigned key = pkeys[i];
     const unsigned h = fmix32(key);
@@ -1733,13 +1788,37 @@ __global__ __launch_bounds__(kJlThreads) void jl_uprobe_kernel(const unsigned *_
         bval = e.y;
         break;
       }
-      if (e.x == kEmptyKey) break;
+      if (e.x == kEmptyKey) {
+        marked |= e.y != kEmptyKey ? 1u : 0u;
+        break;
+      }
       s = jl_next_slot(s);
     }
     // join.cpp:41-43, :96-101: sentinels where the probe row has no partner
     out_key[i] = found ? key : kEmptyKey;
     out_bval[i] = bval;
     out_pval[i] = found ? pvals[i] : kEmptyKey;
+  }
+  if (marked == 0u) return;
+  // a thread that met a spilled partition goes over ITS rows again and answers those of spilled partitions from the pool
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kJlThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned key = pkeys[i];
+    if (key == kEmptyKey) continue;
+    const u32x2 d = spill.dir()[jl_pid(key, parts)];
+    if (d.x == 0u) continue;
+    const unsigned base = d.x - 1u, cap = d.y;
+    unsigned sl = jl_spill_home(key, cap);
+    for (unsigned tries = 0; tries < cap; ++tries) {
+      const unsigned k = spill.keys()[base + sl];
+      if (k == key) {
+        out_key[i] = key;
+        out_bval[i] = spill.pos()[base + sl];
+        out_pval[i] = pvals[i];
+        break;
+      }
+      if (k == kEmptyKey) break;
+      sl = sl + 1 == cap ? 0u : sl + 1;
+    }
   }
 }
 
@@ -1791,6 +1870,25 @@ inline JlShape jl_shape_for(size_t n, unsigned k1, unsigned k2) {
   return sh;
 }
 
+// resident workgroups per CU of `kernel` with `lds` bytes of dynamic LDS: asked of the runtime once per (kernel, lds) and
+// host thread, not on every launch
+inline int jl_resident_blocks(const void *kernel, int threads, size_t lds) {
+  thread_local const void *last_kernel = nullptr;
+  thread_local size_t last_lds = 0;
+  thread_local int last_blocks = 0;
+  if (kernel != last_kernel || lds != last_lds || last_blocks < 1) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, lds) != hipSuccess || blocks < 1) {
+      (void)hipGetLastError();
+      blocks = 1;
+    }
+    last_kernel = kernel;
+    last_lds = lds;
+    last_blocks = blocks;
+  }
+  return last_blocks;
+}
+
 template <bool RANK, bool RIDS, int THREADS, int KPT>
 hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
                                     unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
@@ -1807,12 +1905,7 @@ hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const 
   // persistent grid of the workgroups that are resident (round 4: the 4096-row shape ran with eight per CU where its
   // registers allowed two; held to 80 VGPRs — amdgpu_waves_per_eu(6) — three are, and a grid of exactly those measured
   // 1.5-2 % of the radix join at 2^26 rows: 1759-1777 -> 1726-1740 us on the same box)
-  int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
-    (void)hipGetLastError();
-    blocks = 1;
-  }
-  const size_t per_cu = static_cast<size_t>(blocks);
+  const size_t per_cu = static_cast<size_t>(jl_resident_blocks(reinterpret_cast<const void *>(kernel), THREADS, lds));
   hipLaunchKernelGGL(kernel, dim3(jl_scatter0_grid(tiles, static_cast<size_t>(dev.cus) * per_cu)), dim3(THREADS), lds, s, keys,
                      row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids);
   return hipSuccess;
@@ -1843,11 +1936,7 @@ hipError_t jl_launch_scatter1_shape(hipStream_t s, size_t n, const u32x2 *rows, 
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, THREADS, lds) != hipSuccess || blocks < 1) {
-    (void)hipGetLastError();
-    blocks = 1;
-  }
+  const int blocks = jl_resident_blocks(reinterpret_cast<const void *>(kernel), THREADS, lds);
   const size_t vtiles = ((n + kTile - 1) / kTile + k1 + 7) / 8 * 8;  // every bucket's last tile may be ragged
   size_t grid = static_cast<size_t>(dev.cus) * blocks / 8 * 8;       // the resident workgroups, a whole number per XCD
   if (grid < 8) grid = 8;
@@ -2164,7 +2253,7 @@ int ujoin_lds_build(const unsigned *build_keys, const unsigned *build_vals, size
   const int rc = jl_partition_rows(build_keys, build_vals, n, workspace, s, dev, L, &p);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(jl_ubuild_kernel, dim3(L.parts), dim3(kJlBuildThreads), 0, s, p.keys, p.rids, p.starts, p.table,
-                     p.status);
+                     p.status, jl_spill_of(static_cast<char *>(workspace) + L.spill_off, L.parts, n));
   return launch_status();
 }
 
@@ -2175,7 +2264,8 @@ int ujoin_lds_probe(const unsigned *probe_keys, const unsigned *probe_vals, size
   const u32x2 *table = reinterpret_cast<const u32x2 *>(static_cast<const char *>(workspace) + L.table_off);
   static const int uprobe_wgs = static_cast<int>(jl_resident_per_cu(jl_uprobe_kernel, kJlThreads, 0, "DBHIP_JL_UPROBE_WGS", 4u));
   hipLaunchKernelGGL(jl_uprobe_kernel, dim3(jl_grid(n_probe, dev, uprobe_wgs)), dim3(kJlThreads), 0, s, probe_keys, probe_vals,
-                     n_probe, table, L.parts, out_key, out_bval, out_pval);
+                     n_probe, table, L.parts, out_key, out_bval, out_pval,
+                     jl_spill_of(const_cast<char *>(static_cast<const char *>(workspace)) + L.spill_off, L.parts, n_build));
   return launch_status();
 }
 

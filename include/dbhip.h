@@ -60,11 +60,13 @@ extern "C" {
 #define DBHIP_DEV_SPIN_TIMEOUT 1u  /* dbhip_copy_if_lt_dense_i32 and the single-launch path of dbhip_exclusive_scan_u32:
                                       a chunk waited 2 s for its predecessors (never seen); the output is then wrong */
 #define DBHIP_DEV_KEY_RANGE 2u     /* group key >= groups_count, or the 0xFFFFFFFF sentinel as a join build key */
-#define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot: the bitmask-claimed table, the
-                                      unique-key join's tables.  NOT the one-to-many joins (dbhip_join_build* / _radix_*):
-                                      a partition with more distinct keys than its 3072-slot LDS sub-table holds is built
-                                      in a spill table of its own, any keys join (the one exception: a build of exactly 2^31
-                                      rows has no spare bit to mark such a sub-table and still raises this) */
+#define DBHIP_DEV_TABLE_FULL 4u    /* open-addressing table wrapped without finding a slot: the bitmask-claimed table (a
+                                      table that really is full: the reference spins forever there) and the small-input
+                                      unique-key table.  NOT the LDS-partitioned joins (dbhip_join_build* / _radix_* /
+                                      dbhip_ujoin_* from 2^16 rows): a partition with more distinct keys than its 3072-slot
+                                      LDS sub-table holds is built in a spill table of its own, any keys join (the one
+                                      exception: a one-to-many build of exactly 2^31 rows has no spare bit to mark such a
+                                      sub-table and still raises this) */
 #define DBHIP_DEV_RANK_ORDER 8u    /* radix sort: a tile re-ordered by the pass's digit was not sorted by its lower digits —
                                       the ranking was not stable (or an earlier pass was damaged); the output is wrong */
 

@@ -363,6 +363,34 @@ def test_ujoin_partitioned_path_matches_oracle(n):
     assert 0 < int((ok != 0xFFFFFFFF).sum()) < m  # hits and misses both present
 
 
+@pytest.mark.parametrize("n,crowd", [(1 << 16, 3300), (1 << 18, 9000), (1 << 22, 12000)])
+def test_ujoin_of_a_partition_with_more_keys_than_slots(n, crowd):
+    """Unique build keys of which `crowd` are constructed to fall into ONE partition of the LDS-partitioned build (more than
+    the 3072 slots of its sub-table): that partition is built in the spill pool and probed through the directory — the
+    join's rows are what seq_join gives for any other keys (until round 4: DBHIP_DEV_TABLE_FULL).  Probe: hits and
+    misses inside the spilled partition and elsewhere."""
+    from dwarf_bench_amd import ops
+    rng = np.random.default_rng(43)
+    mine = _keys_of_partition(n, 2, crowd + 400)
+    rest = np.setdiff1d(po.gen_unique_sorted_u32(n, 11), mine)[: n - crowd]
+    ak = np.concatenate([mine[:crowd], rest]).astype(np.uint32)
+    assert np.unique(ak).size == n
+    rng.shuffle(ak)
+    m = n // 2 + 13
+    bk = np.unique(np.concatenate([mine[rng.integers(0, crowd + 400, m // 3)], po.gen_unique_sorted_u32(m, 12)]))[:m].astype(np.uint32)
+    rng.shuffle(bk)
+    av, bv = po.gen_uniform_u32(n, 13, 0, 2**32 - 2), po.gen_uniform_u32(bk.size, 14, 0, 2**32 - 2)
+    plan = ops.UniqueJoin(n, bk.size)
+    plan.build(_dev(ak), _dev(av))
+    plan.probe(_dev(bk), _dev(bv))
+    ok, o1, o2 = (t.cpu().numpy().view(np.uint32) for t in plan.result())  # raises on a non-zero status
+    ek, e1, e2 = po.ujoin(ak, av, bk, bv)
+    assert np.array_equal(ok, ek) and np.array_equal(o1, e1) and np.array_equal(o2, e2)
+    in_crowd = np.isin(bk, mine[:crowd])
+    assert int((ok[in_crowd] != 0xFFFFFFFF).sum()) == int(in_crowd.sum()) > 0  # every probe of a spilled key hits
+    assert int((ok[np.isin(bk, mine[crowd:])] != 0xFFFFFFFF).sum()) == 0          # its neighbours in the partition miss
+
+
 def test_ujoin_baseline_size_properties():
     """2^26 x 2^26 unique keys in [0, 10n): every hit row carries the build payload of ITS key (payload = f(key)),
     the number of hits equals the size of the key-set intersection (torch as an independent cross-check)"""
