@@ -231,6 +231,15 @@ def bench_join(steps, warmup, log2n=26):
     p = _event_times_us(lambda: plan.probe(probe), steps)
     plan.result()
     bu, pu = _drop_max_mean(b), _drop_max_mean(p)
+    # the chip's random-gather rate MEASURED IN THIS RUN with the library's own gather (dbhip_gather_u32: out[i] =
+    # table[idx[i]], 2^26 random 4-byte reads from a 256 MiB table — the access pattern of the probe without its hashing
+    # and its stores of two columns); the figure the fraction below divides by stays the tracked micro-benchmark's
+    import torch
+    table = ops.gen_uniform_u32(1 << 26, 7, 0, 2**32 - 1)
+    idx = ops.gen_uniform_u32(n, 8, 0, (1 << 26) - 1)
+    gu = _drop_max_mean(_event_times_us(lambda: ops.gather_u32(table, idx), max(3, steps)))
+    del table, idx
+    torch.cuda.empty_cache()
     alg = 20 * n  # keys in both sides + ids + (count,pos)
     return {"rows": 2 * n, "build_us": bu, "probe_us": pu, "kernel_us": bu + pu, "mrows_per_s": 2 * n / (bu + pu),
             "algorithmic_bytes": alg, "achieved_gbs": alg / (bu + pu) / 1e3,
@@ -239,7 +248,9 @@ def bench_join(steps, warmup, log2n=26):
             # random 16-B gathers/s from tables >= 64 MiB (tools/ubench.hip), whatever the HBM byte rate
             "roofline_gather": {"bound": "random_gather", "kernel": "jl_probe_kernel", "achieved": n / pu / 1e3,
                                 "peak": RANDOM_GATHER_PEAK_G, "unit": "G gathers/s", "frac": n / pu / 1e3 / RANDOM_GATHER_PEAK_G,
-                                "peak_source": _peak_source()},
+                                "peak_source": _peak_source(),
+                                "gather_rate_measured_in_this_run": {"kernel": "dbhip_gather_u32, 2^26 random 4-byte reads, 256 MiB table",
+                                                                     "g_per_s": n / gu / 1e3, "us": gu}},
             "workload": f"HashJoin build+probe 2^{log2n} x 2^{log2n} uint32 keys (JoinOmnisci semantics)"}
 
 

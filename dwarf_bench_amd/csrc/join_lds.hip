@@ -1344,6 +1344,10 @@ constexpr int kJlGiantThreads = 512;
 __device__ __forceinline__ unsigned jl_giant_slices(const JlGiants &giants, const unsigned long long *__restrict__ starts,
                                                     unsigned *s_first, unsigned *s_wsum, unsigned *ng_out) {
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (giants.max == 0) {  // (uniform) DBHIP_JL_NO_GIANTS=1: no list, this launch only serves the spilled partitions
+    *ng_out = 0;
+    return 0u;
+  }
   unsigned ng = *giants.count();
   ng = ng < giants.max ? ng : giants.max;
   ng = ng < kJlMaxGiantList - 1 ? ng : kJlMaxGiantList - 1;

@@ -222,6 +222,30 @@ def test_many_giant_partitions_of_many_slices_each_count_exactly():
     assert np.array_equal(in_order[pos[hit]], probe[rid[hit]]) and np.array_equal(in_order[pos[hit] + cnt[hit] - 1], probe[rid[hit]])
 
 
+def test_the_no_giants_escape_hatch_still_joins_everything():
+    """DBHIP_JL_NO_GIANTS=1 (every partition through the per-partition kernel whatever its size; read once
+    per process, hence the child process): hot keys are then walked by one workgroup each — slowly, correctly — and a
+    partition with more distinct keys than slots still reaches the spill path, whose launch no longer has a giants' list
+    to look at."""
+    import os, subprocess, sys
+    prog = (
+        "import numpy as np, torch\n"
+        "import tests.test_gpu_join as t\n"
+        "from oracle import pyoracle as po\n"
+        "rng = np.random.default_rng(3)\n"
+        "n = 1 << 18\n"
+        "b = po.gen_uniform_u32(n, 42, 0, n - 1); b[::2] = 777\n"
+        "p = po.gen_uniform_u32(1 << 16, 43, 0, n - 1); p[::5] = 777\n"
+        "t._check_grouped_join(b, p)\n"
+        "b = po.gen_uniform_u32(n, 42, 0, n - 1); mine = t._keys_of_partition(n, 1, 3500)\n"
+        "b[: 3500 * 20] = np.repeat(mine, 20); b = rng.permutation(b); p[::3] = mine[rng.integers(0, 3500, p[::3].size)]\n"
+        "t._check_grouped_join(b, p)\n"
+        "print('no giants ok')\n")
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "DBHIP_JL_NO_GIANTS": "1"}, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0 and "no giants ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def _keys_of_partition_of(parts, partition, how_many):
     cand = np.arange(1, 1 + how_many * parts * 2, dtype=np.uint64)
     mine = cand[(_fmix32(cand) * parts) >> 32 == partition][:how_many]
