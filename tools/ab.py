@@ -15,6 +15,7 @@ the contract numbers come from bench.py.
   sort-shapes [lg] 2^lg keys of eight distributions (few distinct values, sorted, reversed, skewed ...; median of 5)
   join [lg]       build / probe / radix join of 2^lg x 2^lg (drop-max-mean of 7); default lg 26
   radix [lg]      the radix join alone at 2^lg x 2^lg (default 30: the P = 1 point of the partitioned join)
+  radix-sizes     the radix join at 1, 1.25, 1.5, 1.75 x 2^25 .. 2^29 rows (geometry steps)
   join-skew [lg]  the same over key shapes (hot keys, strided keys, sorted, few distinct keys; median of 3)
   size-sweep      every dwarf at sizes next to and between powers of two, 2^13 .. 2^26 (geometry cliffs)
   partition       rank-level partition (dbhip_pjoin_partition_u32) of 2^27 rows into P buckets
@@ -269,6 +270,31 @@ def radix(lg):
           f"ids {'a permutation sum' if ids_ok else 'WRONG'}", flush=True)
 
 
+def radix_sizes(_):
+    """the radix join at sizes between the powers of two (2^25 .. 2^30): ns per row should move smoothly — a row that
+    costs much more than its neighbours is a geometry step (level fan-outs and tile shapes follow the partition count)"""
+    for lg in (25, 26, 27, 28, 29):
+        for num in (4, 5, 6, 7):
+            n = (num << lg) // 4
+            build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+            probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+            rj = ops.RadixJoin(n, n)
+
+            def run():
+                rj.partition_build(build)
+                rj.partition_probe(probe)
+                rj.match()
+
+            r = dropmax(times(run, 5, warm=1))
+            pb = dropmax(times(lambda: rj.partition_build(build), 5, warm=0))
+            rj.result()
+            ok = int(rj.ids.to(torch.int64).sum()) == n * (n - 1) // 2
+            print(f"{TAG:12s} n = {num}/4 * 2^{lg} = {n:11d}: radix join {r:9.1f} us  {r * 1e3 / n:6.3f} ns/row  (partition one side "
+                  f"{pb:8.1f} us) {'ok' if ok else 'WRONG'}", flush=True)
+            del build, probe, rj
+            torch.cuda.empty_cache()
+
+
 def _matches(build, probe):
     """number of (build row, probe row) pairs with equal keys, by torch"""
     bk, bc = torch.unique(u64(build), return_counts=True)
@@ -489,7 +515,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"radix": radix, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
+MODES = {"radix": radix, "radix-sizes": radix_sizes, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
