@@ -188,12 +188,32 @@ def test_native_engine_multi_process_path_with_one_rank():
     from dwarf_bench_amd import pjoin_native
     n = 1 << 20
     eng = pjoin_native.NativePartitionedJoin(n, rank=0, world=1, device=0, nccl_id=pjoin_native.unique_id())
+    info = eng.info()  # what the bench line reports as rccl_ranks_seen / rank_devices: ncclCommCount says one rank here
+    assert info["rccl_ranks_seen"] == 1 and info["world"] == 1 and info["device"] == 0 and info["device_name"]
     for _ in range(2):
         t = eng.step()
-    assert t["exchange_us"] > 0 and t["partition_us"] > 0
+    assert t["exchange_us"] > 0 and t["partition_us"] > 0 and t["exchange_r_us"] > 0 and t["exchange_s_us"] > 0
     chk = eng.check()
     eng.close()
     build = po.gen_uniform_u32(n, 42, 0, n - 1)
     probe = po.gen_uniform_u32(n, 43, 0, n - 1)
     assert chk["bad_pairs"] == chk["bad_route"] == chk["bad_rows"] == 0 and chk["conserved"]
     assert chk["matches"] == int(po.join_counts_fast(build, probe).astype(np.uint64).sum())
+
+
+def test_native_engine_step_keeps_its_six_value_contract():
+    """dbench_pjoin_step (the first form of the call) writes six doubles — a caller built against `double t[6]` must
+    not be overrun by the eight values dbench_pjoin_step_n can deliver"""
+    import ctypes as C
+    from dwarf_bench_amd import pjoin_native
+    lib = pjoin_native.lib()
+    lib.dbench_pjoin_step.restype = C.c_int
+    lib.dbench_pjoin_step.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    eng = pjoin_native.NativePartitionedJoin(1 << 18, rank=0, world=1, device=0, direct_single=False)
+    t = (C.c_double * 8)(*([-1.0] * 8))
+    assert lib.dbench_pjoin_step(eng._h, t) == 0
+    assert all(x >= 0 for x in t[:6]) and t[0] > 0 and t[6] == -1.0 and t[7] == -1.0
+    t3 = (C.c_double * 3)()
+    assert lib.dbench_pjoin_step_n(eng._h, t3, 3) == 3 and t3[0] > 0
+    assert eng.info()["rccl_ranks_seen"] == 0  # one rank without an id: no communicator
+    eng.close()
