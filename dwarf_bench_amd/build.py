@@ -46,16 +46,22 @@ def _run(cmd: list[str], cwd: Path | None = None) -> None:
 
 
 def kernel_tree_sha256() -> str:
-    """Content hash of the device code: every file under csrc/ plus include/dbhip.h, by name and bytes.  The profiler
-    passes that bench.py's `roofline.traffic` comes from record it (tools/profile_summary.py -> profiles/hbm_traffic.json),
-    bench.py reports whether it still matches, and tests/test_bench_contract.py fails when a kernel changed after the
-    counters were collected.  (A content hash rather than `git log -1 -- csrc`: the GPU box has no .git.)"""
+    """Content hash of the device CODE: every file under csrc/ plus include/dbhip.h, by name and by its text with comments
+    and blank space removed (a reworded comment is not a different kernel).  The profiler passes that bench.py's
+    `roofline.traffic` comes from record it (tools/profile_round.sh -> profiles/hbm_traffic.json), bench.py reports whether
+    it still matches, and tests/test_bench_contract.py fails when a kernel changed after the counters were collected.
+    (A content hash rather than `git log -1 -- csrc`: the GPU box has no .git.)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "dbhip.h"]:
+        text = f.read_text()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)   # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                  # line comments (no string literal here holds "//")
+        text = re.sub(r"\s+", " ", text).strip()
         h.update(f.name.encode())
         h.update(b"\0")
-        h.update(f.read_bytes())
+        h.update(text.encode())
         h.update(b"\0")
     return h.hexdigest()
 

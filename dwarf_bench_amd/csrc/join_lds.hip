@@ -965,7 +965,7 @@ __global__ __launch_bounds__(kJlBuildThreads) __attribute__((amdgpu_waves_per_eu
   unsigned *lk = s_lds;                // keys
   unsigned *lc = s_lds + kJlSubSlots;  // counts in step 1; the scan turns the same words into positions:
   unsigned *lp = lc;                   // first id position of the slot, bumped to its end by the fill.
-  // (two arrays instead of three: 48 KiB per workgroup at 6144 slots, three workgroups per CU)
+  // (two arrays instead of three: 24 KiB per workgroup at 3072 slots)
   __shared__ unsigned s_wsum[kJlBuildThreads / kWave];
   __shared__ unsigned s_end;  // where the last slot's id range ends = first position behind the partition's counted rows
   __shared__ unsigned s_ticket;  // the ticket thread 0 took for the partition after the next one
