@@ -8,7 +8,8 @@ namespace dbhip {
 
 // Sub-table geometry (compile-time knobs for experiments).  A partition is expected to hold kJlRowsPerPart rows
 // (Poisson: +-6 sigma = +-270 at 2048) and owns kJlSubSlots slots of an LDS-resident open-addressing table: any
-// number of rows, at most kJlSubSlots DISTINCT keys.  3072 slots for 2048 rows: all-distinct keys (the unique-key
+// number of rows; a partition with more than kJlSubSlots DISTINCT keys (keys constructed against the hash) is built in the
+// spill pool instead (below).  3072 slots for 2048 rows: all-distinct keys (the unique-key
 // join) load the table to 0.67, the uniform one-to-many regime (63 % distinct) to 0.42; the table costs 12 bytes per
 // build row in HBM (4096 slots, the first geometry: 16).  Measured at 2^26 rows, whole build / probe: see DESIGN.md.
 #ifndef DBHIP_JL_SUB_SLOTS

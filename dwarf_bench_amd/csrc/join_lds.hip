@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
 }
 // Destination RANK of the multi-GPU partitioner: a second, independent hash.  It must not be the high bits of
 // fmix32(key) again: a rank only receives keys of one rank bucket, and its local build (jl_pid above) would then
-// find all of them in 1/P of its partitions — P times overfull sub-tables (TABLE_FULL at P = 8).
+// find all of them in 1/P of its partitions — P times overfull sub-tables (at P = 8 more keys than slots: the spill path).
 __device__ __forceinline__ unsigned jl_rank_of(unsigned key, unsigned parts) {
   return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key * 0x9E3779B1u + 0x7F4A7C15u)) * parts) >> 32);
 }

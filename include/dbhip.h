@@ -171,7 +171,11 @@ int dbhip_groupby_merge_u32(uint32_t groups, uint32_t max_private_tables, uint32
  * carrying it gets 0/0.  The table lives in the workspace between build and probe; the
  * probe takes n_build again because the table geometry is a pure function of it.
  * A key may repeat any number of times: the rows of a hot key are shared by all workgroups (from 2^18 build rows
- * on; a build in which every other row carries one key takes 1.3-1.4 x the time of uniform keys).   */
+ * on; a build in which every other row carries one key takes 1.3-1.6 x the time of uniform keys).  ANY keys join,
+ * as with the reference's table (common/dpcpp/omnisci_hashtable.hpp:80-108, ht_size = 2 * distinct keys,
+ * join/join_omnisci.cpp:69-70): keys that crowd one partition of the internal radix partitioning beyond its LDS
+ * sub-table (constructed against the hash: hashed keys never do) are joined through a spill table — slowly,
+ * correctly.  The workspace is 46 bytes per build row (12 table + 16 partition scratch + 18 spill pool).       */
 size_t dbhip_join_workspace_bytes(size_t n_build);
 int dbhip_join_build_u32(const uint32_t *build_keys, size_t n_build, uint32_t *ids, void *workspace,
                          size_t workspace_bytes, dbhip_stream_t stream);
@@ -192,7 +196,7 @@ int dbhip_join_probe_u32(const uint32_t *probe_keys, size_t n_probe, const void 
  * order, each probe row's id (probe_row_ids[i], or i when probe_row_ids is NULL), the offset of its ids and their
  * number.  The three steps are separate entry points so that a host can overlap them with other work (the build
  * side's partition call opens a join: it clears the status word and must come first); dbhip_join_radix_u32 runs all
- * three.  Same contract violations as above (sentinel key, more than 3072 distinct keys in one partition).     */
+ * three.  Same contract as above (the sentinel key is flagged; any other keys join).                              */
 size_t dbhip_join_radix_workspace_bytes(size_t n_build, size_t n_probe);
 int dbhip_join_radix_partition_u32(int probe_side, const uint32_t *keys, const uint32_t *row_ids, size_t n,
                                    size_t n_build, size_t n_probe, void *workspace, size_t workspace_bytes,
