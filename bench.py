@@ -670,21 +670,31 @@ def pjoin_section(args, dist, rank, world, local, barrier, out):
                 section.update({"single_gpu_ms_per_step": c1["ms_per_step"], "single_gpu_mrows_per_s": c1["mrows_per_s"],
                                 "speedup_vs_1gpu": c1["ms_per_step"] / cx["ms_per_step"],
                                 "matches_equal_single_gpu": cx["matches"] == c1["matches"]})
-            # the same join with one and with four sub-joins per step (the figures above are the default, two): how much
-            # of the exchange the pipeline hides on THIS node — one join per step is the schedule of rounds 1-3
-            dog.leg = "C++ engine, all ranks, sub-join sweep"
-            sweep = {}
-            for sj in (1, 4):
-                sx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local, sub_joins=sj)
-                torch.cuda.empty_cache()
-                sweep[str(sj)] = {"ms_per_step": sx["ms_per_step"], "matches": sx["matches"],
-                                  "exchange_links": sx["exchange_links"], "checks": sx["checks"]}
-            if rank == 0:
-                sweep["2"] = {"ms_per_step": cx["ms_per_step"], "matches": cx["matches"]}
-                section["sub_joins_sweep"] = sweep
         except Exception as e:
             if rank == 0:
                 section["error"] = repr(e)
+            cx = None
+        # the same join with one and with four sub-joins per step (the figures above are the default, two): how much of
+        # the exchange the pipeline hides on THIS node — one join per step is the schedule of rounds 1-3.  A leg of its
+        # own: whatever happens here leaves the figures above as they are.
+        if os.environ.get("DBENCH_PJOIN_NO_SWEEP") is None:
+            try:
+                dog.leg = "C++ engine, all ranks, sub-join sweep"
+                agreed = torch.tensor([0 if cx is None else 1], dtype=torch.int64, device="cuda")
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # every rank runs the sweep, or none does
+                if int(agreed.item()) == 0:
+                    raise RuntimeError("skipped: the leg above failed on some rank")
+                sweep = {"2": {"ms_per_step": cx["ms_per_step"], "matches": cx["matches"]}}
+                for sj in (1, 4):
+                    sx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local, sub_joins=sj)
+                    torch.cuda.empty_cache()
+                    sweep[str(sj)] = {"ms_per_step": sx["ms_per_step"], "matches": sx["matches"],
+                                      "exchange_links": sx["exchange_links"], "checks": sx["checks"]}
+                if rank == 0:
+                    section["sub_joins_sweep"] = sweep
+            except Exception as e:
+                if rank == 0:
+                    section["sub_joins_sweep"] = {"error": repr(e)}
     elif rank == 0:
         section["note"] = "rehearsal backend: ranks share GPUs, the C++ RCCL engine needs one GPU per rank and is skipped"
     dog.cancel()
