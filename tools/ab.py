@@ -270,6 +270,134 @@ def radix(lg):
           f"ids {'a permutation sum' if ids_ok else 'WRONG'}", flush=True)
 
 
+def radix_offsets(lg):
+    """does the partition's time depend on WHERE its buffers lie?  One side of the radix join partitioned with the key
+    column and the workspace at different byte offsets inside two larger allocations (the same kernels, the same data)"""
+    lg = lg or 30
+    n = 1 << lg
+    rj = ops.RadixJoin(n, n)
+    slack = 1 << 27
+    big_ws = torch.empty(rj.ws_bytes + slack, dtype=torch.uint8, device="cuda")
+    big_in = torch.empty(n + slack // 4, dtype=torch.int32, device="cuda")
+    src = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    print(f"{TAG:12s} 2^{lg}: workspace {rj.ws_bytes / 2**30:.1f} GiB at {big_ws.data_ptr():#x}, keys at {big_in.data_ptr():#x}", flush=True)
+    for in_off in (0, 4096, 1 << 20, (1 << 21) + (1 << 16), (1 << 26) + (1 << 13)):
+        keys = big_in[in_off // 4: in_off // 4 + n]
+        keys.copy_(src)
+        row = []
+        for ws_off in (0, 256, 4096, 1 << 16, 1 << 20, 1 << 21, (1 << 21) + 4096, 3 << 21, (1 << 25) + (1 << 12), (1 << 26) + (1 << 18)):
+            rj.ws = big_ws[ws_off: ws_off + rj.ws_bytes]
+            t = dropmax(times(lambda: rj.partition_build(keys), 4, warm=1))
+            row.append(f"{t:8.1f}")
+        print(f"{TAG:12s} keys +{in_off:9d} B | workspace +0, +256, +4K, +64K, +1M, +2M, +2M4K, +6M, +32M4K, +64M256K: {' '.join(row)}", flush=True)
+
+
+def radix_alloc(lg):
+    """the same radix join on buffers from torch's allocator and on buffers from plain hipMalloc calls in two orders (the
+    C++ engine allocates that way): does the allocation decide the partition's time?"""
+    import ctypes as C
+    from dwarf_bench_amd import _capi
+    lg = lg or 30
+    n = 1 << lg
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    L = _capi.lib()
+    ws_bytes = L.dbhip_join_radix_workspace_bytes(n, n)
+
+    def raw(size):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), size) == 0
+        return p.value
+
+    def run(label, build, probe, ws, ids, rid, pos, cnt):
+        st = ops._stream()
+        assert L.dbhip_gen_uniform_u32(build, n, 42, 0, 0, n - 1, st) == 0
+        assert L.dbhip_gen_uniform_u32(probe, n, 43, 0, 0, n - 1, st) == 0
+        pb = lambda: _capi.check(L.dbhip_join_radix_partition_u32(0, build, None, n, n, n, ws, ws_bytes, st), "p")
+        pp = lambda: _capi.check(L.dbhip_join_radix_partition_u32(1, probe, None, n, n, n, ws, ws_bytes, st), "p")
+        mm = lambda: _capi.check(L.dbhip_join_radix_match_u32(n, n, ids, rid, pos, cnt, ws, ws_bytes, st), "m")
+
+        def whole():
+            pb(); pp(); mm()
+
+        r = dropmax(times(whole, 4, warm=1))
+        a = dropmax(times(pb, 4, warm=0))
+        b = dropmax(times(pp, 4, warm=0))
+        m = dropmax(times(mm, 4, warm=0))
+        print(f"{TAG:12s} 2^{lg} {label:44s}: radix join {r:9.1f} us (build side {a:8.1f}, probe side {b:8.1f}, match {m:8.1f}) "
+              f"ws at {ws:#x} keys at {build:#x} / {probe:#x}", flush=True)
+
+    t = [ops.gen_uniform_u32(n, 42, 0, n - 1), ops.gen_uniform_u32(n, 43, 0, n - 1), torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")]
+    t += [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(4)]
+    run("torch tensors", *[x.data_ptr() for x in t])
+    del t
+    torch.cuda.empty_cache()
+    for label, order in (("hipMalloc: keys, keys, 512 B, workspace, out", "bpcwo"), ("hipMalloc: workspace first", "wbpco"),
+                         ("hipMalloc: keys, keys, workspace, out (no small)", "bpwo")):
+        got, ptrs = {}, []
+        for ch in order:
+            if ch == "o":
+                for k in ("ids", "rid", "pos", "cnt"):
+                    got[k] = raw(n * 4)
+            else:
+                got[ch] = raw({"b": n * 4, "p": n * 4, "c": 512, "w": ws_bytes}[ch])
+        run(label, got["b"], got["p"], got["w"], got["ids"], got["rid"], got["pos"], got["cnt"])
+        torch.cuda.synchronize()
+        for v in got.values():
+            hip.hipFree(v)
+
+
+def radix_stream(lg):
+    """the radix join on the null stream and on a created (non-blocking) stream, the kind the C++ engine launches on"""
+    lg = lg or 30
+    n = 1 << lg
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    rj = ops.RadixJoin(n, n)
+
+    def run():
+        rj.partition_build(build)
+        rj.partition_probe(probe)
+        rj.match()
+
+    torch.cuda.synchronize()
+    for label, stream in (("null stream", None), ("created stream", torch.cuda.Stream()), ("null stream again", None),
+                          ("created stream again", torch.cuda.Stream())):
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream())
+        with ctx:
+            r = dropmax(times(run, 5, warm=1))
+            pb = dropmax(times(lambda: rj.partition_build(build), 5, warm=0))
+            pp = dropmax(times(lambda: rj.partition_probe(probe), 5, warm=0))
+            m = dropmax(times(rj.match, 5, warm=0))
+        torch.cuda.synchronize()
+        print(f"{TAG:12s} 2^{lg} {label:22s}: radix join {r:9.1f} us (build side {pb:8.1f}, probe side {pp:8.1f}, match {m:8.1f})", flush=True)
+
+
+def radix_idle(lg):
+    """what an idle GPU costs the next join: the radix join timed after the device sat idle for a given time (events
+    around each phase of ONE join; 4 joins per gap, the mean)"""
+    import time
+    lg = lg or 30
+    n = 1 << lg
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(n, 43, 0, n - 1)
+    rj = ops.RadixJoin(n, n)
+    rj.partition_build(build); rj.partition_probe(probe); rj.match()
+    torch.cuda.synchronize()
+    for gap in (0.0, 0.0005, 0.002, 0.01, 0.05, 0.25, 1.0, 0.0):
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(4):
+            torch.cuda.synchronize()
+            time.sleep(gap)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(); rj.partition_build(build); ev[1].record(); rj.partition_probe(probe); ev[2].record(); rj.match(); ev[3].record()
+            torch.cuda.synchronize()
+            for i in range(3):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) * 1e3 / 4
+        print(f"{TAG:12s} 2^{lg} idle {gap * 1e3:7.1f} ms before: radix join {sum(acc):9.1f} us (build side {acc[0]:8.1f}, probe side {acc[1]:8.1f}, match {acc[2]:8.1f})", flush=True)
+
+
 def radix_sizes(_):
     """the radix join at sizes between the powers of two (2^25 .. 2^30): ns per row should move smoothly — a row that
     costs much more than its neighbours is a geometry step (level fan-outs and tile shapes follow the partition count)"""
@@ -515,7 +643,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"radix": radix, "radix-sizes": radix_sizes, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
+MODES = {"radix": radix, "radix-idle": radix_idle, "radix-stream": radix_stream, "radix-alloc": radix_alloc, "radix-offsets": radix_offsets, "radix-sizes": radix_sizes, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
