@@ -398,6 +398,43 @@ def radix_idle(lg):
         print(f"{TAG:12s} 2^{lg} idle {gap * 1e3:7.1f} ms before: radix join {sum(acc):9.1f} us (build side {acc[0]:8.1f}, probe side {acc[1]:8.1f}, match {acc[2]:8.1f})", flush=True)
 
 
+def ramp(_):
+    """how long after an idle period do the dwarfs run slower?  Each dwarf: 100 ms idle, then back-to-back steps with an
+    event between every two; the mean step time over windows of the sequence"""
+    import time
+    n = 1 << 28
+    src = ops.gen_uniform_u32(n, 42, 1, 10000)
+    scan_plan = ops.CopyIfLt(n)
+    gk = ops.gen_uniform_u32(1 << 26, 42, 0, 65535)
+    gv = ops.gen_uniform_u32(1 << 26, 43, 1, 10000)
+    gb = ops.GroupBySum(1 << 26, 1 << 16)
+    k0 = ops.gen_uniform_u32(1 << 24, 42, 0, 2**32 - 1)
+    keys = k0.clone()
+    sp = ops.RadixSort(1 << 24, 8)
+
+    def sort_step():
+        keys.copy_(k0)
+        sp.launch(keys)
+
+    for name, fn, steps in (("scan 2^28", lambda: scan_plan.launch(src, 5), 600), ("group-by 2^26", lambda: gb.launch(gk, gv), 600),
+                            ("sort 2^24 (+ copy)", sort_step, 400)):
+        fn()
+        for idle in (0.1, 0.0):
+            torch.cuda.synchronize()
+            time.sleep(idle)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            ev[0].record()
+            for i in range(steps):
+                fn()
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            t = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(steps)]
+            cum = [ev[0].elapsed_time(ev[i + 1]) for i in range(steps)]
+            wins = [(0, 5), (5, 25), (25, 50), (50, 100), (100, 200), (200, 400), (400, steps)]
+            row = "  ".join(f"[{a}:{b}) {sum(t[a:b]) / (b - a):6.1f}" for a, b in wins if b <= steps and a < b)
+            print(f"{TAG:12s} {name:20s} after {idle * 1e3:5.0f} ms idle, us per step: {row}   (step 25 ends at {cum[24]:.1f} ms, step 100 at {cum[99]:.1f} ms)", flush=True)
+
+
 def radix_sizes(_):
     """the radix join at sizes between the powers of two (2^25 .. 2^30): ns per row should move smoothly — a row that
     costs much more than its neighbours is a geometry step (level fan-outs and tile shapes follow the partition count)"""
@@ -643,7 +680,7 @@ def launch_all(_):
     print("ok")
 
 
-MODES = {"radix": radix, "radix-idle": radix_idle, "radix-stream": radix_stream, "radix-alloc": radix_alloc, "radix-offsets": radix_offsets, "radix-sizes": radix_sizes, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
+MODES = {"radix": radix, "ramp": ramp, "radix-idle": radix_idle, "radix-stream": radix_stream, "radix-alloc": radix_alloc, "radix-offsets": radix_offsets, "radix-sizes": radix_sizes, "graph": graph, "launch-join": launch_join, "launch-sort": launch_sort, "launch-all": launch_all, "scan": scan, "sort": sort, "sort-only": sort_only, "groupby": groupby, "groupby-shapes": groupby_shapes, "groupby-skew": groupby_skew, "sort-shapes": sort_shapes, "join": join, "join-skew": join_skew, "size-sweep": size_sweep, "partition": partition,
          "reduce": reduce, "xscan": xscan}
 
 if __name__ == "__main__":
