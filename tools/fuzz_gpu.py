@@ -10,7 +10,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-done = {"scan": 0, "dense": 0, "sort": 0, "groupby": 0, "xscan": 0, "reduce": 0, "join": 0, "radix_join": 0}
+done = {"scan": 0, "dense": 0, "sort": 0, "groupby": 0, "xscan": 0, "reduce": 0, "join": 0, "radix_join": 0, "crowded": 0, "ujoin": 0}
 
 
 def rand_n():
@@ -39,6 +39,29 @@ def rand_values(n, dtype):
     else:
         v = rng.integers(0, 2**32, n, dtype=np.uint64) & np.uint64(0xFFFF00FF)
     return v.astype(np.uint32).view(dtype)
+
+
+def fmix32_inv(h):
+    """inverse of the joins' key hash (murmur3's 32-bit finaliser is a bijection)"""
+    h = h.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7ED1B41D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h ^= h >> np.uint64(26)
+    h = (h * np.uint64(0xA5CB9243)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h.astype(np.uint32)
+
+
+def crowd(count, bits=None, top=None):
+    """`count` distinct keys whose hashes share their top `bits` bits: whatever the join's geometry, they meet in one
+    partition (or in a few neighbours when it has more than 2^bits partitions) — more keys than an LDS sub-table holds"""
+    bits = int(rng.integers(12, 22)) if bits is None else bits
+    top = int(rng.integers(0, 1 << bits)) if top is None else top
+    space = 1 << (32 - bits)
+    low = rng.choice(space, size=min(count, space), replace=False).astype(np.uint64)
+    keys = fmix32_inv((np.uint64(top) << np.uint64(32 - bits)) | low)
+    return keys[keys != 0xFFFFFFFF], bits, top
 
 
 it = 0
@@ -94,6 +117,17 @@ while time.time() < t_end:
         pk = rng.integers(0, dom, npb, dtype=np.uint64).astype(np.uint32)
         if dom <= 4 and nb > 200_000:  # a handful of keys with hundreds of thousands of rows each: keep it bounded
             bk = bk[:200_000].copy(); nb = bk.size
+        if it % 3 == 0:  # a crowd: thousands of distinct keys in one partition (the spill tables), each with a few rows
+            mine, bits, top = crowd(int(rng.integers(100, 30000)))
+            per = int(rng.integers(1, 12))
+            rows = np.repeat(mine[: max(1, min(mine.size, nb // per))], per)[:nb]
+            bk[: rows.size] = rows
+            bk = rng.permutation(bk)
+            others, _, _ = crowd(2000, bits, top)  # the same partition: some of them build keys, most of them misses
+            pk[::3] = mine[rng.integers(0, mine.size, pk[::3].size)]
+            pk[1::3] = others[rng.integers(0, others.size, pk[1::3].size)]
+            dom = -mine.size
+            done["crowded"] += 1
         uniq, inv_cnt = np.unique(bk, return_counts=True)
         idx = np.searchsorted(uniq, pk)
         idx[idx >= uniq.size] = 0
@@ -120,6 +154,32 @@ while time.time() < t_end:
                 exp_rows = order[starts[idx[r]]: starts[idx[r]] + c]
                 assert np.array_equal(np.sort(rids[rpos[j]: rpos[j] + c]), np.sort(exp_rows)), ("radix join ids", nb, npb, dom, r)
         done["radix_join"] += 1
+    # ---- unique-key payload join: hits carry (key, build value, probe value), misses three 0xFFFFFFFF
+    nu = min(rand_n(), 3_000_000)
+    if nu:
+        if it % 2:
+            uk, _, _ = crowd(min(nu, 200_000), bits=int(rng.integers(8, 14)))
+        else:
+            uk = np.unique(rng.integers(0, int(rng.choice([4 * nu, 2**32 - 1])), nu, dtype=np.uint64).astype(np.uint32))
+        uk = rng.permutation(uk)
+        uv = rng.integers(0, 2**32 - 1, uk.size, dtype=np.uint64).astype(np.uint32)
+        m = min(rand_n(), 3_000_000) or 1
+        qk = rng.integers(0, 2**32 - 1, m, dtype=np.uint64).astype(np.uint32)
+        qk[::2] = uk[rng.integers(0, uk.size, qk[::2].size)]
+        qv = rng.integers(0, 2**32 - 1, m, dtype=np.uint64).astype(np.uint32)
+        uj = ops.UniqueJoin(uk.size, m)
+        uj.build(torch.from_numpy(uk.view(np.int32)).cuda(), torch.from_numpy(uv.view(np.int32)).cuda())
+        uj.probe(torch.from_numpy(qk.view(np.int32)).cuda(), torch.from_numpy(qv.view(np.int32)).cuda())
+        ok_, ob, op_ = (t.cpu().numpy().view(np.uint32) for t in uj.result())
+        srt = np.argsort(uk, kind="stable")
+        at = np.searchsorted(uk[srt], qk)
+        at[at >= uk.size] = 0
+        hit = uk[srt][at] == qk
+        miss = np.uint32(0xFFFFFFFF)
+        assert np.array_equal(ok_, np.where(hit, qk, miss)), ("ujoin keys", uk.size, m)
+        assert np.array_equal(ob, np.where(hit, uv[srt][at], miss)), ("ujoin build vals", uk.size, m)
+        assert np.array_equal(op_, np.where(hit, qv, miss)), ("ujoin probe vals", uk.size, m)
+        done["ujoin"] += 1
     if it % 10 == 0:
         print(f"{it} iterations {done}", flush=True)
 print("fuzz ok", it, done)
