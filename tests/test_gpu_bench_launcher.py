@@ -84,3 +84,38 @@ def test_gpus_2_on_one_gpu_with_rccl_fails_loudly():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "has no GPU of its own" in r.stderr
+
+
+def test_the_rccl_legs_of_the_partitioned_join_section_with_one_rank():
+    """every line of the section's RCCL branch (the C++ engine's legs and the sub-join sweep behind them) runs on this
+    one GPU as a process group of ONE nccl rank — the engine then joins directly, with nothing to exchange, but the
+    section's own code (collectives over the group, the sweep's agreement, the fields it fills) is the code N ranks run"""
+    script = f"""
+import json, sys, types
+sys.path.insert(0, {str(ROOT)!r})
+import torch, torch.distributed as dist
+import bench
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+def barrier():
+    dist.barrier()
+    torch.cuda.synchronize()
+out = {{}}
+bench.pjoin_section(types.SimpleNamespace(steps=2, warmup=1, gpus=1, pjoin_child=False), dist, 0, 1, 0, barrier, out)
+print(json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+    env = {**os.environ, "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29651",
+           "DBENCH_PJOIN_LOG2": "20", "DBENCH_PJOIN_DEADLINE_S": "120", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env.pop("DBENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    pj = json.loads(lines[0])["pjoin"]
+    assert "error" not in pj and "error" not in pj["torch_distributed_host"], pj
+    assert pj["ms_per_step"] > 0 and pj["matches_equal_single_gpu"] and pj["checks"]["all_rows_delivered"], pj
+    sweep = pj["sub_joins_sweep"]
+    assert "error" not in sweep and set(sweep) == {"1", "2", "4"}, sweep
+    assert len({v["matches"] for v in sweep.values()}) == 1 and all(v["ms_per_step"] > 0 for v in sweep.values()), sweep
