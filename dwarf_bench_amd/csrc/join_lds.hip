@@ -50,7 +50,9 @@ constexpr int kJlTile = kJlThreads * kJlKpt;  // 4096 rows per scatter tile, 36 
 #define DBHIP_JL_BUILD_THREADS 512
 #endif
 constexpr int kJlBuildThreads = DBHIP_JL_BUILD_THREADS;  // per-partition build workgroup; 2^26 rows: 512 -> 1398 us,
-                                                        // 256 -> 1514 us, 1024 -> 1465 us (whole build)
+                                                        // 256 -> 1514 us, 1024 -> 1465 us (whole build); round 4, resident
+                                                        // ticketed grid: build 920 / 938 / 1148 us and the radix join's fused
+                                                        // kernel 605 / 700 / 1285 us with 512 / 256 / 1024 threads
 
 __device__ __forceinline__ unsigned jl_pid(unsigned key, unsigned parts) {
   return static_cast<unsigned>((static_cast<unsigned long long>(fmix32(key)) * parts) >> 32);
