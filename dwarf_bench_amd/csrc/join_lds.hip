@@ -418,7 +418,7 @@ struct JlNoHook {
 };
 // before_stores(): called once, right before the tile's global stores are issued (the level-0 kernel waits there for
 // the next tile's prefetched keys: see jl_scatter0_kernel)
-template <int LEVEL, int THREADS, int KPT, bool RANK = false, class Hook = JlNoHook>
+template <int LEVEL, int THREADS, int KPT, bool RANK = false, bool DIGITS = false, class Hook = JlNoHook>
 __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], const unsigned (&rid)[KPT],
                                                 const unsigned (&dest)[KPT], unsigned nb, unsigned parts,
                                                 unsigned arg, unsigned long long *cursors,
@@ -482,7 +482,11 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], cons
     const unsigned pid = jl_pid_sel<RANK>(k, parts);
     const unsigned d = LEVEL == 0 ? pid >> arg : pid & arg;
     const size_t slot = s_base[d] + (p - s_excl[d]);
-    if (out_rids) {  // two columns (the rank-level partition: its outputs go into an all-to-all as they are)
+    if (DIGITS) {  // pairs + the row's level-1 bucket as a 16-bit column of its own (behind `out_rids`): what the level-1
+                   // histogram reads instead of the pairs, 2 bytes per row for 8 (jl_hist1d_kernel)
+      reinterpret_cast<u32x2 *>(out_keys)[slot] = u32x2{k, s_rids[p]};
+      reinterpret_cast<unsigned short *>(out_rids)[slot] = static_cast<unsigned short>(pid & ((1u << arg) - 1u));
+    } else if (out_rids) {  // two columns (the rank-level partition: its outputs go into an all-to-all as they are)
       out_keys[slot] = k;
       out_rids[slot] = s_rids[p];
     } else {  // one array of (key, row id) pairs: one 8-byte store per row, a run of r rows is 8r contiguous bytes
@@ -500,7 +504,7 @@ __device__ __forceinline__ void jl_scatter_tile(const unsigned (&key)[KPT], cons
 #ifndef DBHIP_JL_SC0_WPE
 #define DBHIP_JL_SC0_WPE 6
 #endif
-template <bool RANK, bool RIDS, int THREADS, int KPT>
+template <bool RANK, bool RIDS, int THREADS, int KPT, bool DIGITS = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 && !RIDS ? DBHIP_JL_SC0_WPE : 1))) void jl_scatter0_kernel(const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ row_ids,
                                                                  unsigned long long first_row, size_t n,
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         dest[j] = valid ? jl_pid_sel<RANK>(ckey[j], parts) >> k2_shift : k1;
       }
       // this tile bumps only its group's cursors
-      jl_scatter_tile<0, THREADS, KPT, RANK>(ckey, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem, wait_next);
+      jl_scatter_tile<0, THREADS, KPT, RANK, DIGITS>(ckey, rid, dest, k1, parts, k2_shift, cursors + group * k1, out_keys, out_rids, s_mem, wait_next);
     } else {
       wait_next();
     }
@@ -619,6 +623,52 @@ __global__ __launch_bounds__(kJlThreads) void jl_hist1_kernel(const u32x2 *__res
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (i + j * kJlThreads < hi) atomicAdd(&s_hist[jl_pid(k[j], parts) & (k2 - 1)], 1u);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
+    if (s_hist[i]) atomicAdd(&counts1[static_cast<size_t>(bucket) * k2 + i], static_cast<unsigned long long>(s_hist[i]));
+}
+
+// The same histogram from the 16-bit level-1 bucket column the level-0 scatter wrote beside its pairs (jl_scatter_tile
+// DIGITS; the 16384-row shape, i.e. 2^28 rows and more): 2 bytes per row instead of 8, and no hash.  Eight digits per
+// 16-byte load over the aligned middle of the bucket's range, the ragged ends one digit per lane.
+__global__ __launch_bounds__(kJlThreads) void jl_hist1d_kernel(const unsigned short *__restrict__ digits,
+                                                               const unsigned long long *__restrict__ starts0, unsigned k2,
+                                                               unsigned long long *counts1) {
+  extern __shared__ unsigned s_hist[];
+  const unsigned bucket = blockIdx.x / kJlHist1WgPerBucket, w = blockIdx.x % kJlHist1WgPerBucket;
+  const size_t lo = starts0[bucket], hi = starts0[bucket + 1];
+  if (lo >= hi) return;
+  for (unsigned i = threadIdx.x; i < k2; i += kJlThreads) s_hist[i] = 0;
+  __syncthreads();
+  const unsigned mask = k2 - 1;
+  // head [lo, a) and tail [b, hi) one digit per lane (first workgroup of the bucket), [a, b) in whole 16-byte vectors
+  size_t a = (lo + 7) & ~static_cast<size_t>(7);
+  if (a > hi) a = hi;
+  size_t b = hi & ~static_cast<size_t>(7);
+  if (b < a) b = a;
+  if (w == 0) {
+    for (size_t i = lo + threadIdx.x; i < a; i += kJlThreads) atomicAdd(&s_hist[digits[i] & mask], 1u);
+    for (size_t i = b + threadIdx.x; i < hi; i += kJlThreads) atomicAdd(&s_hist[digits[i] & mask], 1u);
+  }
+  const u32x4 *vec = reinterpret_cast<const u32x4 *>(digits);
+  const size_t va = a / 8, vb = b / 8;
+  for (size_t v = va + static_cast<size_t>(w) * 2 * kJlThreads + threadIdx.x; v < vb;
+       v += static_cast<size_t>(kJlHist1WgPerBucket) * 2 * kJlThreads) {
+    u32x4 x[2];
+    const bool second = v + kJlThreads < vb;
+    x[0] = vec[v];
+    x[1] = second ? vec[v + kJlThreads] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j == 1 && !second) break;
+      const unsigned word[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        atomicAdd(&s_hist[word[q] & mask], 1u);
+        atomicAdd(&s_hist[(word[q] >> 16) & mask], 1u);
+      }
+    }
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < k2; i += kJlThreads)
@@ -1895,13 +1945,13 @@ inline int jl_resident_blocks(const void *kernel, int threads, size_t lds) {
   return last_blocks;
 }
 
-template <bool RANK, bool RIDS, int THREADS, int KPT>
+template <bool RANK, bool RIDS, int THREADS, int KPT, bool DIGITS = false>
 hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
                                     unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
                                     unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids) {
   constexpr unsigned kTile = THREADS * KPT;
   const size_t lds = jl_scatter_lds_bytes(k1, kTile, THREADS);
-  auto kernel = jl_scatter0_kernel<RANK, RIDS, THREADS, KPT>;
+  auto kernel = jl_scatter0_kernel<RANK, RIDS, THREADS, KPT, DIGITS>;
   if (lds > 48 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
@@ -1919,7 +1969,15 @@ hipError_t jl_launch_scatter0_shape(const DeviceInfo &dev, hipStream_t s, const 
 template <bool RANK>
 hipError_t jl_launch_scatter0(int shape, const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
                               unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
-                              unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids) {
+                              unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids, bool digits = false) {
+  // digits: pairs into out_keys AND every row's level-1 bucket as a 16-bit column behind out_rids (16384-row shape only)
+  if (digits) {
+    if (RANK || shape != 2) return hipErrorInvalidValue;
+    return row_ids ? jl_launch_scatter0_shape<false, true, 1024, 16, true>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1,
+                                                                           cursors, out_keys, out_rids)
+                   : jl_launch_scatter0_shape<false, false, 1024, 16, true>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1,
+                                                                            cursors, out_keys, out_rids);
+  }
 #define JL_SC0(RIDS, T, K) \
   jl_launch_scatter0_shape<RANK, RIDS, T, K>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids)
   if (row_ids) {
@@ -2031,15 +2089,25 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   }
   hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, jl_shape_rows(shape.t1), cursors0, starts0,
                      tstarts0, static_cast<unsigned long long *>(nullptr));
+  // A level-1 histogram of its own (no fused one: more than 81920 partitions) behind a level 0 of 16384-row tiles (586+
+  // buckets), i.e. sides of 2^28 rows and more: level 0 writes every row's level-1 bucket as a 16-bit column into the
+  // level-1 output region — unused until the level-1 scatter writes it, like the fused histograms' scratch — and the
+  // histogram reads those 2 bytes per row instead of the 8-byte pairs (DBHIP_JL_DIGITS=0: the pairs, for A/B runs)
+  static const bool digits_on = [] { const char *v = getenv("DBHIP_JL_DIGITS"); return !(v && v[0] == '0'); }();
+  const bool digits = digits_on && k2 > 1 && k2 <= 65536 && !fused && !fused16 && shape.t0 == 2;
   {
     const hipError_t es = jl_launch_scatter0<false>(shape.t0, dev, s, keys, row_ids, 0ull, n, parts, k2_shift, k1, cursors0,
-                                                    reinterpret_cast<unsigned *>(rows_a), static_cast<unsigned *>(nullptr));
+                                                    reinterpret_cast<unsigned *>(rows_a),
+                                                    digits ? reinterpret_cast<unsigned *>(rows_b) : static_cast<unsigned *>(nullptr), digits);
     if (es != hipSuccess) return static_cast<int>(es);
   }
   *out_pairs = reinterpret_cast<const unsigned *>(rows_a);
   *out_starts = starts0;
   if (k2 > 1) {
-    if (!fused && !fused16)
+    if (digits)
+      hipLaunchKernelGGL(jl_hist1d_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
+                         reinterpret_cast<const unsigned short *>(rows_b), starts0, k2, counts1);
+    else if (!fused && !fused16)
       hipLaunchKernelGGL(jl_hist1_kernel, dim3(k1 * kJlHist1WgPerBucket), dim3(kJlThreads), k2 * sizeof(unsigned), s,
                          rows_a, starts0, parts, k2, counts1);
     hipLaunchKernelGGL(jl_offsets1_kernel, dim3(k1), dim3(kJlThreads), 0, s, counts1, starts0, k1, k2, starts1,

@@ -546,3 +546,28 @@ def test_radix_join_carries_caller_row_ids_and_agrees_with_the_probe_path():
     assert ops.check_join(srt, b[(rid.to(torch.int64) - first)].contiguous(), pos, cnt, ids, build_keys=None, gen=(42, 0, n - 1))[0] == 0
     p2, c2, _ = ops.hash_join(a, b)
     assert torch.equal(c2[(rid.to(torch.int64) - first)], cnt)
+
+
+def test_radix_join_whose_level_1_histogram_reads_the_digit_column():
+    """a build side of 2^28 rows and more has more partitions than the fused histograms count (81920) and a level 0 of
+    16384-row tiles: the level-0 scatter then writes every row's level-1 bucket as a 16-bit column and the level-1
+    histogram reads that instead of the pairs (jl_hist1d_kernel).  The probe side is partitioned by the same geometry
+    whatever its size — a few rows per level-0 bucket here, so every bucket's range is mostly ragged ends.  Checked
+    against torch: the count of every probe row, the id buffer as a permutation, first and last id of every hit."""
+    from dwarf_bench_amd import ops
+    n, m = (1 << 28) + 12345, (1 << 22) + 77
+    build = ops.gen_uniform_u32(n, 42, 0, n - 1)
+    probe = ops.gen_uniform_u32(m, 43, 0, n - 1)
+    rid, pos, cnt, ids = ops.radix_join(build, probe)
+    per_key = torch.bincount(build.to(torch.int64), minlength=n)
+    rid64, pos64, cnt64 = rid.to(torch.int64), pos.to(torch.int64) & 0xFFFFFFFF, cnt.to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(torch.sort(rid64).values, torch.arange(m, device=rid.device))
+    keys_of_rows = probe.to(torch.int64)[rid64]
+    assert torch.equal(cnt64, per_key[keys_of_rows])
+    del per_key
+    ids64 = ids.to(torch.int64) & 0xFFFFFFFF
+    assert int(ids64.sum()) == n * (n - 1) // 2 and int(ids64.max()) == n - 1
+    hit = cnt64 > 0
+    b64 = build.to(torch.int64)
+    assert torch.equal(b64[ids64[pos64[hit]]], keys_of_rows[hit])
+    assert torch.equal(b64[ids64[pos64[hit] + cnt64[hit] - 1]], keys_of_rows[hit])
