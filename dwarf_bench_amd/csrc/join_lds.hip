@@ -4,11 +4,13 @@
 //
 // Why: on MI355X a table in HBM costs one memory-side atomic per step (20-27 G/s random, tools/ubench) — three per
 // build row — and three 4-byte gathers per probe row (53 G/s).  Random LDS atomics run at ~4,000 G/s chip-wide
-// (profiles/r03_ubench.txt).  So:
+// (profiles/r04_ubench.txt).  So:
 //   build  1. partition the build column into K = ceil(n / 2048) partitions (join_common.hpp jl_layout) by the mixed hash,
 //             in one or two levels of <= 1024-way scatter (jl_hist / jl_offsets / jl_scatter: LDS counts, one global
 //             reservation per bucket per tile, runs of (key, row id) pairs written contiguously; tiles of 4096 rows,
-//             of 16384 where a level has 512+ buckets: JlShape);
+//             of 16384 where a level has 512+ buckets: JlShape; both histograms from ONE read of the keys up to 81920
+//             partitions, above that level 0 leaves every row's level-1 bucket as a 16-bit column for the level-1
+//             histogram to read instead of the pairs);
 //          2. persistent workgroups — as many as are RESIDENT, partitions dealt by ticket — walk the partitions
 //             (jl_build_kernel): 3072-slot sub-table in LDS (kJlSubSlots) — plain read of the key's slot, ds_cmpst on
 //             an empty one, ONE returning ds_add whose old value is the row's rank inside its key group, LDS exclusive
@@ -1970,13 +1972,14 @@ template <bool RANK>
 hipError_t jl_launch_scatter0(int shape, const DeviceInfo &dev, hipStream_t s, const unsigned *keys, const unsigned *row_ids,
                               unsigned long long first_row, size_t n, unsigned parts, unsigned k2_shift, unsigned k1,
                               unsigned long long *cursors, unsigned *out_keys, unsigned *out_rids, bool digits = false) {
-  // digits: pairs into out_keys AND every row's level-1 bucket as a 16-bit column behind out_rids (16384-row shape only)
+  // digits: pairs into out_keys AND every row's level-1 bucket as a 16-bit column behind out_rids
   if (digits) {
-    if (RANK || shape != 2) return hipErrorInvalidValue;
-    return row_ids ? jl_launch_scatter0_shape<false, true, 1024, 16, true>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1,
-                                                                           cursors, out_keys, out_rids)
-                   : jl_launch_scatter0_shape<false, false, 1024, 16, true>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1,
-                                                                            cursors, out_keys, out_rids);
+    if (RANK) return hipErrorInvalidValue;
+#define JL_SC0D(RIDS, T, K) \
+  jl_launch_scatter0_shape<false, RIDS, T, K, true>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids)
+    if (row_ids) return shape == 0 ? JL_SC0D(true, 512, 8) : shape == 1 ? JL_SC0D(true, 1024, 8) : JL_SC0D(true, 1024, 16);
+    return shape == 0 ? JL_SC0D(false, 512, 8) : shape == 1 ? JL_SC0D(false, 1024, 8) : JL_SC0D(false, 1024, 16);
+#undef JL_SC0D
   }
 #define JL_SC0(RIDS, T, K) \
   jl_launch_scatter0_shape<RANK, RIDS, T, K>(dev, s, keys, row_ids, first_row, n, parts, k2_shift, k1, cursors, out_keys, out_rids)
@@ -2089,12 +2092,13 @@ int jl_partition_side(const unsigned *keys, const unsigned *row_ids, size_t n, u
   }
   hipLaunchKernelGGL(jl_offsets0_kernel, dim3(1), dim3(1024), 0, s, counts0, k1, jl_shape_rows(shape.t1), cursors0, starts0,
                      tstarts0, static_cast<unsigned long long *>(nullptr));
-  // A level-1 histogram of its own (no fused one: more than 81920 partitions) behind a level 0 of 16384-row tiles (586+
-  // buckets), i.e. sides of 2^28 rows and more: level 0 writes every row's level-1 bucket as a 16-bit column into the
-  // level-1 output region — unused until the level-1 scatter writes it, like the fused histograms' scratch — and the
-  // histogram reads those 2 bytes per row instead of the 8-byte pairs (DBHIP_JL_DIGITS=0: the pairs, for A/B runs)
+  // A level-1 histogram of its own (more partitions than the fused ones count: sides of more than 1.47e8 rows): level 0
+  // writes every row's level-1 bucket as a 16-bit column into the level-1 output region — unused until the level-1
+  // scatter writes it, like the fused histograms' scratch — and the histogram reads those 2 bytes per row instead of
+  // the 8-byte pairs: 2^30 x 2^30 26.7-26.8 -> 25.5-25.6 ms, same box (DBHIP_JL_DIGITS=0: the pairs, for A/B runs).
+  // Not below 8192 partitions, where the plain histograms run as well: those sides are a few hundred us as they are.
   static const bool digits_on = [] { const char *v = getenv("DBHIP_JL_DIGITS"); return !(v && v[0] == '0'); }();
-  const bool digits = digits_on && k2 > 1 && k2 <= 65536 && !fused && !fused16 && shape.t0 == 2;
+  const bool digits = digits_on && k2 > 1 && k2 <= 65536 && !fused && !fused16 && parts > kJlFused16MaxParts;
   {
     const hipError_t es = jl_launch_scatter0<false>(shape.t0, dev, s, keys, row_ids, 0ull, n, parts, k2_shift, k1, cursors0,
                                                     reinterpret_cast<unsigned *>(rows_a),

@@ -548,14 +548,16 @@ def test_radix_join_carries_caller_row_ids_and_agrees_with_the_probe_path():
     assert torch.equal(c2[(rid.to(torch.int64) - first)], cnt)
 
 
-def test_radix_join_whose_level_1_histogram_reads_the_digit_column():
-    """a build side of 2^28 rows and more has more partitions than the fused histograms count (81920) and a level 0 of
-    16384-row tiles: the level-0 scatter then writes every row's level-1 bucket as a 16-bit column and the level-1
-    histogram reads that instead of the pairs (jl_hist1d_kernel).  The probe side is partitioned by the same geometry
-    whatever its size — a few rows per level-0 bucket here, so every bucket's range is mostly ragged ends.  Checked
-    against torch: the count of every probe row, the id buffer as a permutation, first and last id of every hit."""
+@pytest.mark.parametrize("n", [160_000_001, (1 << 28) + 12345])
+def test_radix_join_whose_level_1_histogram_reads_the_digit_column(n):
+    """a build side of more than 1.47e8 rows has more partitions than the fused histograms count (81920): the level-0
+    scatter then writes every row's level-1 bucket as a 16-bit column and the level-1 histogram reads that instead of
+    the pairs (jl_hist1d_kernel) — with 4096-row tiles (349 x 256 buckets) at the first size, 16384-row tiles
+    (586 x 256) at the second.  The probe side is partitioned by the same geometry whatever its size — a few thousand
+    rows per level-0 bucket here, so the ragged ends of every bucket's range count.  Checked against torch: the count
+    of every probe row, the id buffer as a permutation, first and last id of every hit."""
     from dwarf_bench_amd import ops
-    n, m = (1 << 28) + 12345, (1 << 22) + 77
+    m = (1 << 22) + 77
     build = ops.gen_uniform_u32(n, 42, 0, n - 1)
     probe = ops.gen_uniform_u32(m, 43, 0, n - 1)
     rid, pos, cnt, ids = ops.radix_join(build, probe)
