@@ -573,3 +573,15 @@ def test_radix_join_whose_level_1_histogram_reads_the_digit_column(n):
     b64 = build.to(torch.int64)
     assert torch.equal(b64[ids64[pos64[hit]]], keys_of_rows[hit])
     assert torch.equal(b64[ids64[pos64[hit] + cnt64[hit] - 1]], keys_of_rows[hit])
+    del rid, pos, cnt, ids, rid64, pos64, cnt64, ids64, keys_of_rows, hit
+    torch.cuda.empty_cache()
+    # the row-ordered join partitions its build side through the same code (2048 rows per partition)
+    pos, cnt, ids = ops.hash_join(build, probe)
+    per_key = torch.bincount(b64, minlength=n)
+    p64 = probe.to(torch.int64)
+    cnt64, pos64, ids64 = cnt.to(torch.int64) & 0xFFFFFFFF, pos.to(torch.int64) & 0xFFFFFFFF, ids.to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(cnt64, per_key[p64])
+    assert int(ids64.sum()) == n * (n - 1) // 2
+    hit = cnt64 > 0
+    assert torch.equal(b64[ids64[pos64[hit]]], p64[hit])
+    assert torch.equal(b64[ids64[pos64[hit] + cnt64[hit] - 1]], p64[hit])
