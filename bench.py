@@ -692,9 +692,33 @@ def pjoin_section(args, dist, rank, world, local, barrier, out):
                                       "exchange_links": sx["exchange_links"], "checks": sx["checks"]}
                 if rank == 0:
                     section["sub_joins_sweep"] = sweep
+                # The number of sub-joins is a knob of the engine (Options::sub_joins, DWARF_BENCH_PJOIN_SUBJOINS); which
+                # value hides most of the exchange depends on the node's links.  The figures above (the default, two)
+                # are safe by now: if another count was clearly faster in the sweep, the join is measured once more
+                # with it, at the full number of steps, and THAT becomes the section's figure — with the count and the
+                # default's time stated.  (Every rank sees the same all-reduced times, so every rank decides alike.)
+                margin = float(os.environ.get("DBENCH_PJOIN_RERUN_MARGIN", "0.97"))
+                best = min(("1", "4"), key=lambda k: sweep[k]["ms_per_step"])
+                rerun = sweep[best]["ms_per_step"] < margin * cx["ms_per_step"]
             except Exception as e:
+                rerun = False
                 if rank == 0:
                     section["sub_joins_sweep"] = {"error": repr(e)}
+            if rerun:
+                try:
+                    dog.leg = f"C++ engine, all ranks, {best} sub-joins"
+                    bx = bench_pjoin_native(pj_steps, pj_warm, pj_log2, dist, rank, world, local, sub_joins=int(best))
+                    torch.cuda.empty_cache()
+                    if rank == 0 and bx["matches"] == cx["matches"] and bx["ms_per_step"] < cx["ms_per_step"]:
+                        single = section.get("single_gpu_ms_per_step")
+                        section.update(bx)
+                        section["sub_joins_chosen_by"] = (f"the sweep on this node: {best} sub-joins per step; the engine's default "
+                                                          f"(2) took {cx['ms_per_step']:.3f} ms per step in this run")
+                        if single:
+                            section["speedup_vs_1gpu"] = single / bx["ms_per_step"]
+                except Exception as e:
+                    if rank == 0:
+                        section["sub_joins_rerun_error"] = repr(e)
     elif rank == 0:
         section["note"] = "rehearsal backend: ranks share GPUs, the C++ RCCL engine needs one GPU per rank and is skipped"
     dog.cancel()
